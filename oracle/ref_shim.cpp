@@ -1,0 +1,139 @@
+// TEST INFRASTRUCTURE ONLY — never linked into, imported by, or called from the product path.
+//
+// Thin C-ABI shim around the *unmodified* reference headers, compiled where they lie under
+// /root/reference/include (nothing is copied into this repository).  The resulting
+// oracle/_ref/libans_ref.so is used to (1) validate the clean-room restatement in
+// oracle/ans_oracle.c, (2) generate tests/golden/ fixtures, (3) optionally serve as the
+// "reference" CPU baseline in bench.py.
+//
+// Include order matters: ans_fold.hpp uses constants::K / RADIX / RADIX_LOG2, which
+// only exist once ans_byte.hpp has been seen (that is what methods.hpp:29 does).
+// The wrappers below restate methods.hpp:529-567 (ANSfold<f>/ANSrfold<f>::encode/decode) — those
+// three-line forwarding functions cannot be included directly because methods.hpp also pulls in
+// un-vendored third-party headers (FastPFor, streamvbyte, FSE).
+//
+// Build: see oracle/Makefile (clang++ -ftrivial-auto-var-init=zero => canonical zero padding for
+// the indeterminate bits of the last interpolative word).
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "ans_byte.hpp"
+#include "ans_fold.hpp"
+#include "ans_reorder_fold.hpp"
+
+namespace {
+
+template <uint32_t f>
+size_t fold_enc(const uint32_t* in, size_t n, uint8_t* out, size_t cap)
+{
+    return ans_fold_compress<f>(out, cap, in, n); // methods.hpp:535-540
+}
+template <uint32_t f>
+void fold_dec(const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
+{
+    ans_fold_decompress<f>(out, n, in, nbytes); // methods.hpp:541-546
+}
+template <uint32_t f>
+size_t rfold_enc(const uint32_t* in, size_t n, uint8_t* out, size_t cap)
+{
+    return ans_reorder_fold_compress<f>(out, cap, in, n); // methods.hpp:555-560
+}
+template <uint32_t f>
+void rfold_dec(const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
+{
+    ans_reorder_fold_decompress<f>(out, n, in, nbytes); // methods.hpp:561-566
+}
+
+} // namespace
+
+#define DISPATCH_F(fn, ...)                                                    \
+    switch (f) {                                                               \
+    case 1: return fn<1>(__VA_ARGS__);                                         \
+    case 2: return fn<2>(__VA_ARGS__);                                         \
+    case 3: return fn<3>(__VA_ARGS__);                                         \
+    case 4: return fn<4>(__VA_ARGS__);                                         \
+    case 5: return fn<5>(__VA_ARGS__);                                         \
+    case 6: return fn<6>(__VA_ARGS__);                                         \
+    case 7: return fn<7>(__VA_ARGS__);                                         \
+    default: break;                                                            \
+    }
+
+extern "C" {
+
+// kind: 0 = ANSfold<f>, 1 = ANSrfold<f>
+size_t ref_encode(int kind, int f, const uint32_t* in, size_t n, uint8_t* out, size_t cap)
+{
+    if (kind == 0) {
+        DISPATCH_F(fold_enc, in, n, out, cap)
+    } else {
+        DISPATCH_F(rfold_enc, in, n, out, cap)
+    }
+    return 0;
+}
+
+void ref_decode(int kind, int f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
+{
+    if (kind == 0) {
+        DISPATCH_F(fold_dec, in, nbytes, out, n)
+    } else {
+        DISPATCH_F(rfold_dec, in, nbytes, out, n)
+    }
+}
+
+// adjust_freqs(freqs, largest_sym, require_u16=true) — ans_util.hpp:100-157.
+// freqs has nfreqs entries; writes largest_sym+1 normalised freqs; returns the frame size M.
+uint64_t ref_adjust_freqs(const uint64_t* freqs, size_t nfreqs, uint32_t largest_sym, uint32_t* scaled_out)
+{
+    std::vector<uint64_t> F(freqs, freqs + nfreqs);
+    auto S = adjust_freqs(F, largest_sym, true);
+    uint64_t M = 0;
+    for (size_t i = 0; i < S.size(); i++) {
+        scaled_out[i] = S[i];
+        M += S[i];
+    }
+    return M;
+}
+
+// ans_serialize_interp — ans_util.hpp:46-63.  Returns total prelude bytes (vbyte + 1 + interp words).
+size_t ref_serialize_prelude(const uint32_t* nfreqs, size_t nsyms, uint64_t frame_size, uint8_t* out)
+{
+    std::vector<uint32_t> v(nfreqs, nfreqs + nsyms);
+    uint8_t* p = out;
+    ans_serialize_interp(v, frame_size, p);
+    return size_t(p - out);
+}
+
+// ans_load_interp — ans_util.hpp:25-42.  Returns number of symbols (max_sym+1).
+size_t ref_load_prelude(const uint8_t* in, uint32_t* nfreqs_out)
+{
+    auto v = ans_load_interp(in);
+    for (size_t i = 0; i < v.size(); i++) nfreqs_out[i] = v[i];
+    return v.size();
+}
+
+uint32_t ref_fold_mapping(int f, uint32_t x)
+{
+    DISPATCH_F(ans_fold_mapping, x)
+    return 0;
+}
+
+uint32_t ref_fold_undo_mapping(int f, uint32_t s)
+{
+    DISPATCH_F(ans_fold_undo_mapping, s)
+    return 0;
+}
+
+uint32_t ref_fold_exception_bytes(int f, uint32_t s)
+{
+    DISPATCH_F(ans_fold_exception_bytes, s)
+    return 0;
+}
+
+} // extern "C"

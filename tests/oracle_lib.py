@@ -1,0 +1,229 @@
+"""ctypes bindings for the CHECKERS (test infrastructure only):
+
+* ``oracle/libans_oracle.so``  — clean-room C restatement (oracle/ans_oracle.c)
+* ``oracle/_ref/libans_ref.so`` — the unmodified reference headers (oracle/ref_shim.cpp), when built
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+FOLD, RFOLD = 0, 1
+
+
+class OracleInfo(C.Structure):
+    _fields_ = [
+        ("max_sym", C.c_uint32),
+        ("log2_frame", C.c_uint32),
+        ("header_bytes", C.c_uint32),
+        ("prelude_bytes", C.c_uint32),
+        ("interp_bits", C.c_uint32),
+        ("reorder_flag", C.c_uint32),
+        ("sigma", C.c_uint64),
+        ("final_states", C.c_uint64 * 4),
+    ]
+
+
+def build_oracle():
+    """Compile the C restatement (and, when /root/reference is present, oracle/_ref)."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+def _load_oracle():
+    path = os.path.join(ORACLE_DIR, "libans_oracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    lib = C.CDLL(path)
+    lib.ans_oracle_fold.restype = C.c_uint32
+    lib.ans_oracle_fold.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ans_oracle_unfold.restype = C.c_uint32
+    lib.ans_oracle_unfold.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ans_oracle_adjust_freqs.restype = C.c_uint64
+    lib.ans_oracle_adjust_freqs.argtypes = [_u64p, C.c_size_t, C.c_uint32, _u32p]
+    lib.ans_oracle_write_prelude.restype = C.c_size_t
+    lib.ans_oracle_write_prelude.argtypes = [_u32p, C.c_size_t, C.c_uint64, _u8p, C.POINTER(C.c_uint32)]
+    lib.ans_oracle_read_prelude.restype = C.c_size_t
+    lib.ans_oracle_read_prelude.argtypes = [_u8p, _u32p, C.POINTER(C.c_uint32)]
+    lib.ans_oracle_encode.restype = C.c_size_t
+    lib.ans_oracle_encode.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_size_t, _u8p, C.c_size_t,
+                                      C.POINTER(OracleInfo), C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_size_t)]
+    lib.ans_oracle_decode.restype = C.c_int
+    lib.ans_oracle_decode.argtypes = [C.c_int, C.c_uint32, _u8p, C.c_size_t, _u32p, C.c_size_t, C.c_int]
+    lib.ans_oracle_bound.restype = C.c_size_t
+    lib.ans_oracle_bound.argtypes = [C.c_int, C.c_uint32, C.c_size_t]
+    return lib
+
+
+def _load_ref(name="libans_ref.so"):
+    path = os.path.join(ORACLE_DIR, "_ref", name)
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.ref_encode.restype = C.c_size_t
+    lib.ref_encode.argtypes = [C.c_int, C.c_int, _u32p, C.c_size_t, _u8p, C.c_size_t]
+    lib.ref_decode.restype = None
+    lib.ref_decode.argtypes = [C.c_int, C.c_int, _u8p, C.c_size_t, _u32p, C.c_size_t]
+    lib.ref_adjust_freqs.restype = C.c_uint64
+    lib.ref_adjust_freqs.argtypes = [_u64p, C.c_size_t, C.c_uint32, _u32p]
+    lib.ref_serialize_prelude.restype = C.c_size_t
+    lib.ref_serialize_prelude.argtypes = [_u32p, C.c_size_t, C.c_uint64, _u8p]
+    lib.ref_load_prelude.restype = C.c_size_t
+    lib.ref_load_prelude.argtypes = [_u8p, _u32p]
+    for fn in ("ref_fold_mapping", "ref_fold_undo_mapping", "ref_fold_exception_bytes"):
+        getattr(lib, fn).restype = C.c_uint32
+        getattr(lib, fn).argtypes = [C.c_int, C.c_uint32]
+    return lib
+
+
+_oracle = None
+_ref = {}
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = _load_oracle()
+    return _oracle
+
+
+def ref(name="libans_ref.so"):
+    if name not in _ref:
+        _ref[name] = _load_ref(name)
+    return _ref[name]
+
+
+def have_ref():
+    return ref() is not None
+
+
+# ---------------------------------------------------------------- convenience wrappers
+
+def oracle_encode(kind, f, data, ckpt_interval=0):
+    """Returns (stream bytes as np.uint8, OracleInfo, ckpt_states[nck,4] u64, ckpt_off[nck] u32)."""
+    data = np.ascontiguousarray(data, dtype=np.uint32)
+    n = data.size
+    cap = oracle().ans_oracle_bound(kind, f, n)
+    out = np.zeros(cap, dtype=np.uint8)
+    info = OracleInfo()
+    nck_max = (n // ckpt_interval + 1) if ckpt_interval else 1
+    st = np.zeros((nck_max, 4), dtype=np.uint64)
+    off = np.zeros(nck_max, dtype=np.uint32)
+    nck = C.c_size_t(0)
+    nb = oracle().ans_oracle_encode(kind, f, data, n, out, cap, C.byref(info), ckpt_interval,
+                                    st.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                    C.byref(nck))
+    if nb == 0:
+        raise RuntimeError("oracle encode failed")
+    return out[:nb].copy(), info, st[: nck.value].copy(), off[: nck.value].copy()
+
+
+def oracle_decode(kind, f, stream, n, ref_f3_compat=False):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    # the reader may look a few bytes past the prelude; pad defensively
+    padded = np.concatenate([stream, np.zeros(16, dtype=np.uint8)])
+    out = np.zeros(n, dtype=np.uint32)
+    rc = oracle().ans_oracle_decode(kind, f, padded, stream.size, out, n, int(ref_f3_compat))
+    if rc != 0:
+        raise RuntimeError("oracle decode failed rc=%d" % rc)
+    return out
+
+
+def ref_encode(kind, f, data, lib="libans_ref.so"):
+    data = np.ascontiguousarray(data, dtype=np.uint32)
+    n = data.size
+    cap = oracle().ans_oracle_bound(kind, f, n) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    nb = ref(lib).ref_encode(kind, f, data, n, out, cap)
+    return out[:nb].copy()
+
+
+def ref_decode(kind, f, stream, n):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    padded = np.concatenate([np.zeros(16, dtype=np.uint8), stream, np.zeros(16, dtype=np.uint8)])
+    view = padded[16:16 + stream.size]
+    out = np.zeros(n, dtype=np.uint32)
+    ref().ref_decode(kind, f, np.ascontiguousarray(view), stream.size, out, n)
+    return out
+
+
+# ---------------------------------------------------------------- seeded input families
+
+def gen_inputs(name, n, seed=0):
+    """Deterministic integer-only-friendly input families used across the parity tests."""
+    rng = np.random.default_rng(seed)
+    if name == "uniform256":
+        return rng.integers(1, 257, size=n, dtype=np.uint32)
+    if name == "uniform12":
+        return rng.integers(0, 1 << 12, size=n, dtype=np.uint32)
+    if name == "uniform20":
+        return rng.integers(0, 1 << 20, size=n, dtype=np.uint32)
+    if name == "uniform24":
+        return rng.integers(0, 1 << 24, size=n, dtype=np.uint32)
+    if name == "geom0.01":
+        return (rng.geometric(0.01, size=n) - 1).astype(np.uint32)
+    if name == "geom0.4":
+        return (rng.geometric(0.4, size=n) - 1).astype(np.uint32)
+    if name.startswith("zipf"):
+        # zipf<log2N>[s<exp>], inverse-CDF sampling over {1..N}
+        body = name[4:]
+        if "s" in body:
+            lg, s = body.split("s")
+            s = float(s)
+        else:
+            lg, s = body, 1.0
+        N = 1 << int(lg)
+        w = 1.0 / np.power(np.arange(1, N + 1, dtype=np.float64), s)
+        cdf = np.cumsum(w)
+        cdf /= cdf[-1]
+        u = rng.random(n)
+        return (np.searchsorted(cdf, u, side="left") + 1).astype(np.uint32)
+    if name == "constant":
+        return np.full(n, 7, dtype=np.uint32)
+    if name == "distinct":
+        return (np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 30)).astype(np.uint32)
+    if name == "sparse_large":
+        v = rng.integers(0, 1 << 30, size=n, dtype=np.uint32)
+        mask = rng.random(n) < 0.9
+        v[mask] = rng.integers(0, 50, size=int(mask.sum()), dtype=np.uint32)
+        return v
+    if name == "boundaries":
+        vals = []
+        for f in (1, 3, 5):
+            T = 1 << (f + 7)
+            for k in range(0, 4):
+                b = T << (8 * k)
+                for d in (-2, -1, 0, 1, 2):
+                    x = b + d
+                    if 0 <= x < (1 << 30):
+                        vals.append(x)
+        vals += [0, 1, (1 << 30) - 1, (1 << 30) - 2]
+        vals = np.array(vals, dtype=np.uint32)
+        return vals[rng.integers(0, vals.size, size=n)]
+    raise ValueError(name)
+
+
+def canonicalize(stream, info):
+    """Zero the indeterminate padding bits of the last interpolative word.
+
+    The reference's bit writer leaves bits >= (interp_bits % 32) of the final prelude word
+    unspecified (uninitialised stack / stale window contents, include/bits.hpp:146-216), so
+    byte parity is defined modulo exactly those bits."""
+    s = np.array(stream, dtype=np.uint8, copy=True)
+    vb = info.interp_bits % 32
+    if vb != 0:
+        end = info.header_bytes + info.prelude_bytes
+        w = int.from_bytes(s[end - 4:end].tobytes(), "little") & ((1 << vb) - 1)
+        s[end - 4:end] = np.frombuffer(w.to_bytes(4, "little"), dtype=np.uint8)
+    return s

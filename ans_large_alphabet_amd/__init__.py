@@ -1,0 +1,13 @@
+"""ans_large_alphabet_amd — MI355X-native ANSfold / ANSrfold encode+decode path.
+
+Product code: csrc/ (HIP kernels + C-ABI, built into libansx.so), include/ (C++17 mirror of the
+reference's methods.hpp codec structs), and this ctypes host mirror.  Nothing here imports the
+test oracle (oracle/), and there is no CPU fallback.
+"""
+from ._lib import (AnsxError, DEFAULT_BLOCK_INTS, DEFAULT_CKPT_INTERVAL, FOLD, NO_CHECKPOINTS,
+                   RFOLD, SINGLE_STREAM, build_library, lib)
+from .codec import ANSfold, ANSrfold, Context, make_opts, parse_container
+
+__all__ = ["ANSfold", "ANSrfold", "Context", "AnsxError", "build_library", "lib", "make_opts",
+           "parse_container", "FOLD", "RFOLD", "SINGLE_STREAM", "NO_CHECKPOINTS",
+           "DEFAULT_BLOCK_INTS", "DEFAULT_CKPT_INTERVAL"]

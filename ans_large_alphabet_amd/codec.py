@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's codec concept for this path.
+
+The reference exposes ``ANSfold<f>`` / ``ANSrfold<f>`` as structs with static ``name()``,
+``encode(in, n, out, cap)`` -> bytes written and ``decode(in, bytes, out, n)``
+(/root/reference/include/methods.hpp:529-567).  The classes below keep those names and argument
+meanings on top of the C-ABI (include/ansx.h); the C++17 mirror with the exact static
+signatures is ans_large_alphabet_amd/include/ansx_methods.hpp.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def make_opts(block_ints=0, ckpt_interval=0):
+    return L.Opts(block_ints, ckpt_interval, 0, 0)
+
+
+class Context:
+    """One per (process, device): owns the HIP stream and the device workspace."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        st = L.lib().ansx_init(device, C.byref(self._h))
+        if st != L.OK:
+            raise L.AnsxError(st, "ansx_init")
+
+    def close(self):
+        if self._h:
+            L.lib().ansx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def workspace_bytes(self):
+        return L.lib().ansx_workspace_bytes(self._h)
+
+    # -- per-kernel timing (hipEvents inside the library)
+    def profile(self, on=True):
+        L.lib().ansx_profile_enable(self._h, int(on))
+
+    def profile_reset(self):
+        L.lib().ansx_profile_reset(self._h)
+
+    def profile_get(self):
+        arr = (L.KernelTime * 64)()
+        cnt = C.c_int(0)
+        L.lib().ansx_profile_get(self._h, arr, 64, C.byref(cnt))
+        return [(arr[i].name.decode(), arr[i].total_ms, int(arr[i].launches)) for i in range(min(cnt.value, 64))]
+
+
+class _Codec:
+    KIND = L.FOLD
+    PREFIX = "ANSfold"
+
+    def __init__(self, fidelity, ctx=None, block_ints=0, ckpt_interval=0):
+        self.f = int(fidelity)
+        self.ctx = ctx
+        self.opts = make_opts(block_ints, ckpt_interval)
+
+    def _ctx(self):
+        if self.ctx is None:
+            self.ctx = Context()
+        return self.ctx
+
+    def name(self):  # methods.hpp:530-533 / 550-553
+        buf = C.create_string_buffer(32)
+        L.lib().ansx_codec_name(self.KIND, self.f, buf, 32)
+        return buf.value.decode()
+
+    def bound(self, n):
+        return L.lib().ansx_bound(self.KIND, self.f, n, C.byref(self.opts))
+
+    # ---- host buffers (numpy), signature meaning as methods.hpp encode()/decode()
+    def encode(self, data, out=None):
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        n = data.size
+        if out is None:
+            out = np.empty(max(self.bound(n), 64), dtype=np.uint8)
+        nb = C.c_size_t(0)
+        st = L.lib().ansx_encode(self._ctx().handle, self.KIND, self.f, data.ctypes.data, n,
+                                 out.ctypes.data, out.size, C.byref(nb), C.byref(self.opts))
+        if st != L.OK:
+            raise L.AnsxError(st, self.name() + ".encode")
+        return out[: nb.value]
+
+    def decode(self, stream, n, out=None):
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        if out is None:
+            out = np.empty(n, dtype=np.uint32)
+        st = L.lib().ansx_decode(self._ctx().handle, self.KIND, self.f, stream.ctypes.data, stream.size,
+                                 out.ctypes.data, n, C.byref(self.opts))
+        if st != L.OK:
+            raise L.AnsxError(st, self.name() + ".decode")
+        return out
+
+    # ---- device pointers (HBM resident); ptrs are integers (e.g. torch.Tensor.data_ptr())
+    def encode_dev(self, in_ptr, n, out_ptr, out_capacity, stream=None):
+        nb = C.c_size_t(0)
+        st = L.lib().ansx_encode_dev(self._ctx().handle, self.KIND, self.f, in_ptr, n, out_ptr,
+                                     out_capacity, C.byref(nb), C.byref(self.opts), stream)
+        if st != L.OK:
+            raise L.AnsxError(st, self.name() + ".encode_dev")
+        return nb.value
+
+    def decode_dev(self, in_ptr, in_bytes, out_ptr, n, stream=None):
+        st = L.lib().ansx_decode_dev(self._ctx().handle, self.KIND, self.f, in_ptr, in_bytes, out_ptr, n,
+                                     C.byref(self.opts), stream)
+        if st != L.OK:
+            raise L.AnsxError(st, self.name() + ".decode_dev")
+
+
+class ANSfold(_Codec):
+    """methods.hpp:529-547"""
+    KIND = L.FOLD
+    PREFIX = "ANSfold"
+
+
+class ANSrfold(_Codec):
+    """methods.hpp:549-567"""
+    KIND = L.RFOLD
+    PREFIX = "ANSrfold"
+
+
+# ---------------------------------------------------------------- container parsing (host)
+
+def parse_container(buf):
+    """Split a container (np.uint8) into header fields, per-block streams and restart points."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    H = L.ContainerHeader()
+    st = L.lib().ansx_container_info(buf.ctypes.data, buf.size, C.byref(H))
+    if st != L.OK:
+        raise L.AnsxError(st, "ansx_container_info")
+    nb = H.nblocks
+    idx_off = C.sizeof(L.ContainerHeader)
+    boff = np.frombuffer(buf[idx_off: idx_off + 8 * (nb + 1)].tobytes(), dtype=np.uint64)
+    ck_off_off = idx_off + 8 * (nb + 1)
+    nck = nb * H.ckpts_per_block
+    ck_off = np.frombuffer(buf[ck_off_off: ck_off_off + 4 * nck].tobytes(), dtype=np.uint32)
+    ck_state_off = (ck_off_off + 4 * nck + 7) // 8 * 8
+    ck_state = np.frombuffer(buf[ck_state_off: ck_state_off + 32 * nck].tobytes(), dtype=np.uint64)
+    p0 = int(H.payload_offset)
+    streams = [buf[p0 + int(boff[i]): p0 + int(boff[i + 1])] for i in range(nb)]
+    return {
+        "header": H, "block_off": boff, "streams": streams,
+        "ckpt_off": ck_off.reshape(nb, H.ckpts_per_block) if nck else ck_off.reshape(nb, 0),
+        "ckpt_state": ck_state.reshape(nb, H.ckpts_per_block, 4) if nck else ck_state.reshape(nb, 0, 4),
+    }

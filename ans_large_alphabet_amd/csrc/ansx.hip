@@ -1,0 +1,673 @@
+// ansx — host side of the C-ABI (include/ansx.h): context, device workspace, launch sequences.
+// Everything that computes runs in the HIP kernels of ansx_kernels.h / ansx_rfold.h; there is no
+// CPU fallback: if no gfx950 device is usable, ansx_init fails with ANSX_ERR_NO_DEVICE.
+#include "../../include/ansx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ansx_kernels.h"
+#include "ansx_rfold.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+struct Layout {  // container layout, a pure function of the geometry
+    u64 index_off, ckoff_off, ckstate_off, payload_off;
+};
+
+}  // namespace
+
+struct ansx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    bool profile = false;
+    std::vector<ProfRec> recs;
+    std::map<std::string, std::pair<double, u64>> acc;
+    std::vector<std::string> order;
+    DevBuf hist, sortF, sortSym, attS, prevS, attMeta, blk, table, scratch, misc, mapped, mostfreq,
+        stage_in, stage_out, dec_s2s, dec_cum, plain, rf_tmp;
+    u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (call);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            (ctx)->last_hip = (int)_e;                                                           \
+            return ANSX_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+int ensure(ansx_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return ANSX_OK;
+    if (b.p) {
+        hipError_t e = hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        if (e != hipSuccess) {
+            c->last_hip = (int)e;
+            return ANSX_ERR_HIP;
+        }
+    }
+    size_t want = bytes + (bytes >> 3) + 4096;  // a little headroom against re-allocation
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        return ANSX_ERR_HIP;
+    }
+    b.cap = want;
+    return ANSX_OK;
+}
+
+void prof_begin(ansx_ctx* c, const char* name, hipStream_t s)
+{
+    if (!c->profile) return;
+    ProfRec r;
+    r.name = name;
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, s);
+    c->recs.push_back(r);
+}
+void prof_end(ansx_ctx* c, hipStream_t s)
+{
+    if (!c->profile) return;
+    (void)hipEventRecord(c->recs.back().e1, s);
+}
+
+#define LAUNCH(ctx, name, kern, grid, block, shmem, strm, ...)                                   \
+    do {                                                                                         \
+        prof_begin(ctx, name, strm);                                                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), strm, __VA_ARGS__);           \
+        prof_end(ctx, strm);                                                                     \
+        HIPCHK(ctx, hipGetLastError());                                                          \
+    } while (0)
+
+inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// worst-case bytes of one block's reference stream
+size_t block_bound(int kind, u32 f, size_t nb)
+{
+    size_t hdr = kind == ANSX_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
+    return hdr + 8 + 4 * (size_t)fold_NSP(f) + 7 * nb + 32;
+}
+
+struct Plan {
+    ansx_geo g;
+    bool plain;
+    Layout lay;
+    u32 NSP;
+};
+
+int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
+{
+    if (kind != ANSX_FOLD && kind != ANSX_RFOLD) return ANSX_ERR_ARG;
+    if (f < 1 || f > 7) return ANSX_ERR_ARG;
+    if (n == 0) return ANSX_ERR_ARG;
+    u32 bi = opts ? opts->block_ints : 0;
+    u32 ck = opts ? opts->ckpt_interval : 0;
+    if (opts && opts->flags) return ANSX_ERR_ARG;
+    P->plain = (bi == ANSX_SINGLE_STREAM);
+    if (bi == 0) bi = ANSX_DEFAULT_BLOCK_INTS;
+    if (ck == 0) ck = ANSX_DEFAULT_CKPT_INTERVAL;
+    if (ck == ANSX_NO_CHECKPOINTS) ck = 0;
+    if (P->plain) {
+        if (n >= ((size_t)1 << 31)) return ANSX_ERR_ARG;  // reference limit
+        bi = (u32)n;
+        ck = 0;
+    } else {
+        if (bi & 3u) return ANSX_ERR_ARG;
+        if (bi >= (1u << 31)) return ANSX_ERR_ARG;
+    }
+    if (ck & 3u) return ANSX_ERR_ARG;
+    if (ck >= bi) ck = 0;
+    size_t nblocks = (n + bi - 1) / bi;
+    if (nblocks > 0x7FFFFFFFull) return ANSX_ERR_ARG;
+    ansx_geo g;
+    g.n = n;
+    g.block_ints = bi;
+    g.nblocks = (u32)nblocks;
+    g.ckpt = ck;
+    g.nckf = geo_nseg(bi, ck) - 1;
+    g.f = (u32)f;
+    g.kind = (u32)kind;
+    P->g = g;
+    P->NSP = fold_NSP((u32)f);
+    Layout L;
+    L.index_off = sizeof(ansx_container_header);
+    L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
+    L.ckstate_off = rup(L.ckoff_off + 4 * (u64)g.nblocks * g.nckf, 8);
+    L.payload_off = rup(L.ckstate_off + 32 * (u64)g.nblocks * g.nckf, 16);
+    if (P->plain) L.index_off = L.ckoff_off = L.ckstate_off = L.payload_off = 0;
+    P->lay = L;
+    return ANSX_OK;
+}
+
+int flags_to_status(u32 fl)
+{
+    if (fl & (1u << 6)) return ANSX_ERR_DOMAIN;
+    if (fl & (1u << 7)) return ANSX_ERR_MODEL;
+    if (fl & (1u << 2)) return ANSX_ERR_CAPACITY;
+    if (fl & (1u << 3)) return ANSX_ERR_FORMAT;
+    return ANSX_OK;
+}
+
+// --------------------------------------------------------------------------------- rfold
+// ans_reorder_fold.hpp:70-106 on the device.  One workgroup sorts one block in LDS, so the
+// block must fit: block_ints <= 16384 (whole-list ANSrfold of longer inputs needs a global
+// sort and is not built yet — callers get ANSX_ERR_ARG).
+int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u32* mostfreq,
+    ansx_blk* blk, u32* gflags, hipStream_t s)
+{
+    if (g.block_ints > 16384u) return ANSX_ERR_ARG;
+    u32 N2 = 2;
+    while (N2 < g.block_ints) N2 <<= 1;
+    const u32 T = fold_T(g.f);
+    size_t lds = 6 * (size_t)N2 + 8 * (size_t)T + 16;
+    if (lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAUNCH(c, "k_rfold_remap", k_rfold_remap, g.nblocks, 256, lds, s, d_in, g, N2, mapped, mostfreq,
+        blk, gflags);
+    return ANSX_OK;
+}
+
+// --------------------------------------------------------------------------------- encode
+int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap,
+    size_t* out_bytes, hipStream_t s)
+{
+    const ansx_geo& g = P.g;
+    const u32 NB = g.nblocks, NSP = P.NSP, f = g.f;
+    const size_t scr_stride = rup(block_bound(g.kind, f, g.block_ints) + 16, 256);
+    if (!P.plain && cap < P.lay.payload_off) return ANSX_ERR_CAPACITY;
+    int rc;
+    if ((rc = ensure(c, c->hist, (size_t)NB * NSP * 4))) return rc;
+    if ((rc = ensure(c, c->sortF, (size_t)NB * NSP * 4))) return rc;
+    if ((rc = ensure(c, c->sortSym, (size_t)NB * NSP * 2))) return rc;
+    if ((rc = ensure(c, c->attS, (size_t)NB * ANSX_ATTEMPTS * NSP * 2))) return rc;
+    if ((rc = ensure(c, c->prevS, (size_t)NB * NSP * 2))) return rc;
+    if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 8))) return rc;
+    if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
+    if ((rc = ensure(c, c->table, (size_t)NB * NSP * sizeof(ansx_enc_entry)))) return rc;
+    if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
+    if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
+    u32* gflags = (u32*)c->misc.p;
+    u64* result = (u64*)((u8*)c->misc.p + 16);
+    u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
+    ansx_blk* blk = (ansx_blk*)c->blk.p;
+    u32* hist = (u32*)c->hist.p;
+
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
+    HIPCHK(c, hipMemsetAsync(blk, 0, (size_t)NB * sizeof(ansx_blk), s));
+
+    const u32* src = d_in;
+    const u32* mostfreq = nullptr;
+    if (g.kind == ANSX_RFOLD) {
+        const u32 T = fold_T(f);
+        if ((rc = ensure(c, c->mapped, (size_t)g.n * 4))) return rc;
+        if ((rc = ensure(c, c->mostfreq, (size_t)NB * T * 4))) return rc;
+        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s);
+        if (rc) return rc;
+        src = (const u32*)c->mapped.p;
+        mostfreq = (const u32*)c->mostfreq.p;
+    }
+
+    // K1
+    u32 chunk = g.block_ints < 16384u ? g.block_ints : 16384u;
+    if (chunk & 3u) chunk = (chunk + 3u) & ~3u;
+    const u32 cpb = (g.block_ints + chunk - 1) / chunk;
+    if (cpb > 1) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)NB * NSP * 4, s));
+    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * 4, s, src, g, chunk, cpb, NSP,
+        hist, blk, gflags, 1u << 30);
+    // K2
+    if ((size_t)NSP * 8 + 8192 > 48 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 8192)));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
+    }
+    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 256, (size_t)NSP * 8 + 8192, s, g, NSP, hist,
+        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
+    const u32 nbatch = 3;
+    for (u32 batch = 0; batch < nbatch; batch++) {
+        LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
+            0, s, g, NSP, batch, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
+            (u16*)c->attS.p, (u32*)c->attMeta.p);
+        LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
+            (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
+            (ansx_enc_entry*)c->table.p, gflags, batch == nbatch - 1 ? 1u : 0u);
+    }
+    // K3
+    LAUNCH(c, "k_write_prelude", k_write_prelude, NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
+        (const ansx_enc_entry*)c->table.p, hist, blk, (u8*)c->scratch.p, (u64)scr_stride, mostfreq);
+    // K5
+    u64* ck_state = P.plain ? nullptr : (u64*)(d_out + P.lay.ckstate_off);
+    u32* ck_off = P.plain ? nullptr : (u32*)(d_out + P.lay.ckoff_off);
+    LAUNCH(c, "k_encode", k_encode, ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
+        (const ansx_enc_entry*)c->table.p, blk, (u8*)c->scratch.p, (u64)scr_stride, ck_state, ck_off);
+    // K6
+    u64* boff = P.plain ? boff_ws : (u64*)(d_out + P.lay.index_off);
+    LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off,
+        (u64)cap, gflags);
+    LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p,
+        (u64)scr_stride, d_out + P.lay.payload_off, gflags);
+    if (!P.plain)
+        LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int st = flags_to_status(c->h_pin[ANSX_G_ERR]);
+    if (st) return st;
+    u64 payload;
+    memcpy(&payload, (u8*)c->h_pin + 16, 8);
+    *out_bytes = (size_t)(P.lay.payload_off + payload);
+    return ANSX_OK;
+}
+
+// --------------------------------------------------------------------------------- decode
+template <bool RF>
+int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
+    const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
+    u32* gflags, hipStream_t s)
+{
+    const u32 T = fold_T(g.f);
+    const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
+    u32 threads = (u32)rup((size_t)nseg * 4, 64);
+    if (threads > 256) threads = 256;
+    size_t cb = rup(((size_t)max_ns + 2) * 4, 16);
+    size_t lds = cb + rup((size_t)maxM * 2, 16) + (RF ? (size_t)T * 4 : 0);
+    const size_t LDS_LIMIT = 150 * 1024;
+    if (lds <= LDS_LIMIT) {
+        if (lds > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode<true, RF>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_decode", (k_decode<true, RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
+            ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u16*)nullptr, (u32*)nullptr, gflags);
+    } else {
+        int rc;
+        if ((rc = ensure(c, c->dec_s2s, (size_t)g.nblocks * maxM * 2))) return rc;
+        if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
+        size_t l2 = RF ? (size_t)T * 4 : 16;
+        if (l2 > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode<false, RF>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+        LAUNCH(c, "k_decode_gtab", (k_decode<false, RF>), g.nblocks, threads, l2, s, cont, g, NSP, boff,
+            ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u16*)c->dec_s2s.p, (u32*)c->dec_cum.p,
+            gflags);
+    }
+    return ANSX_OK;
+}
+
+__global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 payload_bytes,
+    u32* __restrict__ gflags)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.nblocks) return;
+    u64 a = boff[i], b = boff[i + 1];
+    bool bad = (b < a) || (b - a) < 38 || (b - a) >= (1ull << 31) || b > payload_bytes;
+    if (i == 0 && a != 0) bad = true;
+    if (i == g.nblocks - 1 && b != payload_bytes) bad = true;
+    if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+}
+
+int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
+{
+    if (bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
+    ansx_container_header H;
+    memcpy(&H, h, sizeof(H));
+    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
+    if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
+    if (H.kind > 1 || H.fidelity < 1 || H.fidelity > 7 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
+    *out = H;
+    return ANSX_OK;
+}
+
+int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u32* d_out,
+    hipStream_t s)
+{
+    Plan P = Pin;
+    int rc;
+    if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)P.g.nblocks + 1)))) return rc;
+    u32* gflags = (u32*)c->misc.p;
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
+    const u32 f = P.g.f;
+    const u32 T = fold_T(f);
+    u32 maxM, max_ns;
+    const u8* cont;
+    const u64* boff;
+    const u64* ck_state = nullptr;
+    const u32* ck_off = nullptr;
+    u64 payload_off;
+    if (P.plain) {
+        // one reference stream: copy behind a 16-byte guard (the decoder reads 8 bytes below
+        // its cursor) and peek max_sym / log2 M on the host
+        if (in_bytes < 38) return ANSX_ERR_FORMAT;
+        if ((rc = ensure(c, c->plain, in_bytes + 64))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->plain.p, 0, 16, s));
+        HIPCHK(c, hipMemcpyAsync((u8*)c->plain.p + 16, d_in, in_bytes, hipMemcpyDeviceToDevice, s));
+        size_t peek = in_bytes < 16 ? in_bytes : 16;
+        u8* hp = (u8*)c->h_pin + 64;
+        HIPCHK(c, hipMemcpyAsync(hp, d_in, peek, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        size_t pos = 0;
+        if (P.g.kind == ANSX_RFOLD) {
+            u32 flag;
+            memcpy(&flag, hp, 4);
+            if (flag > 1) return ANSX_ERR_FORMAT;
+            pos = 4 + (flag ? 4 * (size_t)T : 0);
+            if (pos + 8 > in_bytes) return ANSX_ERR_FORMAT;
+            if (flag) {
+                HIPCHK(c, hipMemcpyAsync(hp, d_in + pos, 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                pos = 0;
+            }
+        }
+        u32 ms = 0, sh = 0;
+        for (int i = 0; i < 5; i++) {
+            u8 cb = hp[pos++];
+            ms += (u32)(cb & 127) << sh;
+            if (!(cb & 128)) break;
+            sh += 7;
+        }
+        u32 lg = hp[pos];
+        if (ms >= P.NSP || lg > 31) return ANSX_ERR_FORMAT;
+        maxM = 1u << lg;
+        max_ns = ms + 1;
+        u64 hb[2] = { 0, (u64)in_bytes };
+        u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
+        HIPCHK(c, hipMemcpyAsync(boff_ws, hb, 16, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));  // hb is a stack buffer
+        cont = (const u8*)c->plain.p;
+        boff = boff_ws;
+        payload_off = 16;
+    } else {
+        u8* hp = (u8*)c->h_pin + 64;
+        if (in_bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
+        HIPCHK(c, hipMemcpyAsync(hp, d_in, sizeof(ansx_container_header), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        ansx_container_header H;
+        if ((rc = parse_header(hp, in_bytes, &H))) return rc;
+        if (H.kind != P.g.kind || H.fidelity != f || H.n != P.g.n) return ANSX_ERR_FORMAT;
+        // the container, not the caller's options, defines the geometry
+        ansx_opts o;
+        o.block_ints = H.block_ints;
+        o.ckpt_interval = H.ckpt_interval ? H.ckpt_interval : ANSX_NO_CHECKPOINTS;
+        o.flags = 0;
+        o.reserved = 0;
+        if (H.block_ints == ANSX_SINGLE_STREAM) return ANSX_ERR_FORMAT;
+        if ((rc = make_plan((int)H.kind, (int)f, (size_t)H.n, &o, &P))) return ANSX_ERR_FORMAT;
+        if (P.g.nblocks != H.nblocks || P.g.nckf != H.ckpts_per_block || P.g.ckpt != H.ckpt_interval
+            || P.lay.payload_off != H.payload_offset)
+            return ANSX_ERR_FORMAT;
+        if (H.payload_offset + H.payload_bytes > in_bytes) return ANSX_ERR_FORMAT;
+        if (H.max_log2_frame > 31 || H.max_nsyms == 0 || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
+        maxM = 1u << H.max_log2_frame;
+        max_ns = H.max_nsyms;
+        cont = d_in;
+        boff = (const u64*)(d_in + P.lay.index_off);
+        ck_state = (const u64*)(d_in + P.lay.ckstate_off);
+        ck_off = (const u32*)(d_in + P.lay.ckoff_off);
+        payload_off = H.payload_offset;
+        LAUNCH(c, "k_validate_index", k_validate_index, (P.g.nblocks + 255) / 256, 256, 0, s, P.g, boff,
+            H.payload_bytes, gflags);
+        // the index must be sane before any block is touched
+        HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
+    }
+    if (P.g.kind == ANSX_RFOLD)
+        rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
+            max_ns, gflags, s);
+    else
+        rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
+            max_ns, gflags, s);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return flags_to_status(c->h_pin[ANSX_G_ERR]);
+}
+
+}  // namespace
+
+// ================================================================================= C ABI
+extern "C" {
+
+int ansx_init(int device, ansx_ctx** out)
+{
+    if (!out) return ANSX_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ANSX_ERR_NO_DEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return ANSX_ERR_NO_DEVICE;
+    }
+    if (device >= ndev) return ANSX_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ANSX_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ANSX_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ANSX_ERR_NO_DEVICE;  // gfx950-only code object
+    ansx_ctx* c = new ansx_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ANSX_ERR_HIP;
+    }
+    if (hipHostMalloc((void**)&c->h_pin, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return ANSX_ERR_HIP;
+    }
+    *out = c;
+    return ANSX_OK;
+}
+
+void ansx_destroy(ansx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+        &c->table, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
+        &c->dec_s2s, &c->dec_cum, &c->plain, &c->rf_tmp };
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& r : c->recs) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ansx_strerror(int st)
+{
+    switch (st) {
+    case ANSX_OK: return "ok";
+    case ANSX_ERR_ARG: return "invalid argument";
+    case ANSX_ERR_CAPACITY: return "output buffer too small";
+    case ANSX_ERR_FORMAT: return "malformed container or stream";
+    case ANSX_ERR_HIP: return "HIP runtime error";
+    case ANSX_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case ANSX_ERR_DOMAIN: return "input value outside [0, 2^30)";
+    case ANSX_ERR_MODEL: return "frequency normalisation hit the reference's degenerate exit";
+    default: return "unknown status";
+    }
+}
+
+int ansx_last_hip_error(const ansx_ctx* c) { return c ? c->last_hip : 0; }
+
+int ansx_codec_name(int kind, int f, char* buf, size_t buflen)
+{
+    return snprintf(buf, buflen, "%s-%d", kind == ANSX_RFOLD ? "ANSrfold" : "ANSfold", f);
+}
+
+size_t ansx_bound(int kind, int f, size_t n, const ansx_opts* opts)
+{
+    Plan P;
+    if (make_plan(kind, f, n, opts, &P)) return 0;
+    size_t per = block_bound(kind, (u32)f, 0);
+    return (size_t)P.lay.payload_off + (size_t)P.g.nblocks * per + 7 * n + 64;
+}
+
+int ansx_encode_dev(ansx_ctx* c, int kind, int f, const uint32_t* d_in, size_t n, uint8_t* d_out,
+    size_t cap, size_t* out_bytes, const ansx_opts* opts, void* stream)
+{
+    if (!c || !d_in || !d_out || !out_bytes) return ANSX_ERR_ARG;
+    if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_in & 3u)) return ANSX_ERR_ARG;
+    Plan P;
+    int rc = make_plan(kind, f, n, opts, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return encode_dev(c, P, d_in, d_out, cap, out_bytes, s);
+}
+
+int ansx_decode_dev(ansx_ctx* c, int kind, int f, const uint8_t* d_in, size_t in_bytes,
+    uint32_t* d_out, size_t n, const ansx_opts* opts, void* stream)
+{
+    if (!c || !d_in || !d_out) return ANSX_ERR_ARG;
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ANSX_ERR_ARG;
+    Plan P;
+    int rc = make_plan(kind, f, n, opts, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return decode_dev(c, P, d_in, in_bytes, d_out, s);
+}
+
+int ansx_encode(ansx_ctx* c, int kind, int f, const uint32_t* in, size_t n, uint8_t* out, size_t cap,
+    size_t* out_bytes, const ansx_opts* opts)
+{
+    if (!c || !in || !out || !out_bytes) return ANSX_ERR_ARG;
+    Plan P;
+    int rc = make_plan(kind, f, n, opts, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t bound = ansx_bound(kind, f, n, opts);
+    size_t dcap = cap < bound ? cap : bound;
+    if ((rc = ensure(c, c->stage_in, n * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->stage_out, dcap + 64))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->stage_in.p, in, n * 4, hipMemcpyHostToDevice, s));
+    size_t nb = 0;
+    rc = encode_dev(c, P, (const u32*)c->stage_in.p, (u8*)c->stage_out.p, dcap, &nb, s);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, nb, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *out_bytes = nb;
+    return ANSX_OK;
+}
+
+int ansx_decode(ansx_ctx* c, int kind, int f, const uint8_t* in, size_t in_bytes, uint32_t* out,
+    size_t n, const ansx_opts* opts)
+{
+    if (!c || !in || !out) return ANSX_ERR_ARG;
+    Plan P;
+    int rc = make_plan(kind, f, n, opts, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure(c, c->stage_out, in_bytes + 64))) return rc;
+    if ((rc = ensure(c, c->stage_in, n * 4 + 16))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->stage_out.p, in, in_bytes, hipMemcpyHostToDevice, s));
+    rc = decode_dev(c, P, (const u8*)c->stage_out.p, in_bytes, (u32*)c->stage_in.p, s);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_in.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ANSX_OK;
+}
+
+int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out)
+{
+    if (!container || !out) return ANSX_ERR_ARG;
+    return parse_header(container, bytes, out);
+}
+
+int ansx_profile_enable(ansx_ctx* c, int on)
+{
+    if (!c) return ANSX_ERR_ARG;
+    c->profile = on != 0;
+    return ANSX_OK;
+}
+
+static void prof_collect(ansx_ctx* c)
+{
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        auto it = c->acc.find(r.name);
+        if (it == c->acc.end()) {
+            c->order.push_back(r.name);
+            c->acc[r.name] = std::make_pair((double)ms, (u64)1);
+        } else {
+            it->second.first += ms;
+            it->second.second += 1;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    c->recs.clear();
+}
+
+int ansx_profile_reset(ansx_ctx* c)
+{
+    if (!c) return ANSX_ERR_ARG;
+    prof_collect(c);
+    c->acc.clear();
+    c->order.clear();
+    return ANSX_OK;
+}
+
+int ansx_profile_get(ansx_ctx* c, ansx_kernel_time* out, int max_entries, int* count)
+{
+    if (!c || !count) return ANSX_ERR_ARG;
+    prof_collect(c);
+    int k = 0;
+    for (auto& name : c->order) {
+        if (out && k < max_entries) {
+            memset(&out[k], 0, sizeof(out[k]));
+            strncpy(out[k].name, name.c_str(), sizeof(out[k].name) - 1);
+            out[k].total_ms = c->acc[name].first;
+            out[k].launches = c->acc[name].second;
+        }
+        k++;
+    }
+    *count = k;
+    return ANSX_OK;
+}
+
+size_t ansx_workspace_bytes(const ansx_ctx* c)
+{
+    if (!c) return 0;
+    const DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+        &c->table, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
+        &c->dec_s2s, &c->dec_cum, &c->plain, &c->rf_tmp };
+    size_t t = 0;
+    for (const DevBuf* b : bufs) t += b->cap;
+    return t;
+}
+
+double ansx_host_log2(double x) { return ansx_log2_portable(x); }
+
+}  // extern "C"

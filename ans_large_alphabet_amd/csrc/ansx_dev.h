@@ -1,0 +1,189 @@
+// Device/host helpers shared by every ansx kernel (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ANSX_HD __host__ __device__ __forceinline__
+#define ANSX_D __device__ __forceinline__
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// ---------------------------------------------------------------------------------------------
+// Constants of the reference codec (include/ans_byte.hpp:24-31 as used by ans_fold.hpp)
+// ---------------------------------------------------------------------------------------------
+#define ANSX_K_LOG2 4          // K = 16: lower bound L = 16*M
+#define ANSX_RADIX_LOG2 32     // renormalise in 32-bit words
+#define ANSX_U16_LIMIT 65535u  // ans_util.hpp:126
+
+// fold geometry (include/ans_fold.hpp:38-50): threshold T = 2^(f+7), per-byte offset D = 255*2^(f-1)
+ANSX_HD u32 fold_T(u32 f) { return 1u << (f + 7); }
+ANSX_HD u32 fold_D(u32 f) { return 255u << (f - 1); }
+ANSX_HD u32 fold_NSP(u32 f) { return 1u << (f + 9); }  // symbol-array stride = reference MAX_SIGMA (ans_fold.hpp:70)
+
+// Closed form of the reference's byte-stripping loop (ans_fold.hpp:38-65): number of exception
+// bytes k and folded symbol.  Valid for all 32-bit x because T >= 256.
+ANSX_HD u32 fold_nbytes(u32 f, u32 x)
+{
+    const u32 T = fold_T(f);
+    // x >= T, x >= 256T, x >= 65536T ; 65536*T may exceed 2^32 only for f >= 9 (out of scope)
+    u32 k = (x >= T) ? 1u : 0u;
+    k += ((x >> 8) >= T) ? 1u : 0u;
+    k += ((x >> 16) >= T) ? 1u : 0u;
+    return k;
+}
+ANSX_HD u32 fold_sym(u32 f, u32 x, u32 k) { return (x >> (8 * k)) + k * fold_D(f); }
+
+// include/ans_fold.hpp:150-175
+ANSX_HD u32 unfold_nbytes(u32 f, u32 sym)
+{
+    const u32 T = fold_T(f), D = fold_D(f);
+    u32 k = (sym >= T) ? 1u : 0u;
+    k += (sym >= T + D) ? 1u : 0u;
+    k += (sym >= T + 2 * D) ? 1u : 0u;
+    return k;
+}
+ANSX_HD u32 unfold_value(u32 f, u32 sym, u32 k) { return (sym - k * fold_D(f)) << (8 * k); }
+
+// ---------------------------------------------------------------------------------------------
+// Portable log2: only IEEE +,-,*,/ and fma, identical on host and device.  Replaces glibc's
+// log2 in entropy()/cross_entropy() (include/util.hpp:271-298).  Accuracy ~1 ulp; exact for
+// powers of two.  The normaliser compares sums of ~10^3 such terms against a 0.1 % margin
+// (ans_util.hpp:127-128,149), so the last-ulp difference to glibc only matters when
+// |XH - 1.001 H| < ~1e-15 H, where the reference's own decision depends on the libm build.
+// ---------------------------------------------------------------------------------------------
+ANSX_HD double ansx_bits_to_f64(u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b);
+#else
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return d;
+#endif
+}
+ANSX_HD u64 ansx_f64_to_bits(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u64)__double_as_longlong(d);
+#else
+    u64 b;
+    __builtin_memcpy(&b, &d, 8);
+    return b;
+#endif
+}
+
+#pragma clang fp contract(off)
+ANSX_HD double ansx_log2_portable(double x)
+{
+    // x is a ratio of positive integers < 2^53: positive, finite, normal.
+    u64 ix = ansx_f64_to_bits(x);
+    int e = (int)(ix >> 52) - 1023;
+    u64 m = (ix & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double z = ansx_bits_to_f64(m);  // [1,2)
+    if (z > 1.4142135623730951) {
+        z = z * 0.5;
+        e += 1;
+    }
+    double f = z - 1.0;  // exact
+    double s = f / (2.0 + f);
+    double s2 = s * s;
+    // log(z) = 2s * (1 + s2/3 + s2^2/5 + ...); |s| <= 0.1716 -> s2 <= 0.02944; 12 terms < 2^-60
+    double p = 1.0 / 25.0;
+    p = __builtin_fma(p, s2, 1.0 / 23.0);
+    p = __builtin_fma(p, s2, 1.0 / 21.0);
+    p = __builtin_fma(p, s2, 1.0 / 19.0);
+    p = __builtin_fma(p, s2, 1.0 / 17.0);
+    p = __builtin_fma(p, s2, 1.0 / 15.0);
+    p = __builtin_fma(p, s2, 1.0 / 13.0);
+    p = __builtin_fma(p, s2, 1.0 / 11.0);
+    p = __builtin_fma(p, s2, 1.0 / 9.0);
+    p = __builtin_fma(p, s2, 1.0 / 7.0);
+    p = __builtin_fma(p, s2, 1.0 / 5.0);
+    p = __builtin_fma(p, s2, 1.0 / 3.0);
+    p = p * s2;  // s2/3 + s2^2/5 + ...
+    double t = 2.0 * s;
+    // residual of the division, including the rounding of den = 2 + f (Fast2Sum, |f| < 2):
+    //   f = s*(den + dlo) + r   ->   s_exact = s + (r - s*dlo)/den
+    double den = 2.0 + f;
+    double dlo = f - (den - 2.0);
+    double r = __builtin_fma(-s, den, f);
+    r = __builtin_fma(-s, dlo, r);
+    double tlo = __builtin_fma(t, p, 2.0 * (r / den));  // low part of log(z)
+    // log2(z) = (t + tlo) / ln2, in two pieces
+    const double IL2_HI = 1.4426950408889634;       // 1/ln2 rounded to double
+    const double IL2_LO = 2.0355273740931033e-17;   // 1/ln2 - IL2_HI
+    double y = t * IL2_HI;
+    double ye = __builtin_fma(t, IL2_HI, -y);
+    double ylo = __builtin_fma(tlo, IL2_HI, __builtin_fma(t, IL2_LO, ye));
+    // e + y with Fast2Sum (e == 0 or |e| >= 1 > |y|)
+    double ed = (double)e;
+    double hi = ed + y;
+    double herr = y - (hi - ed);
+    return hi + (herr + ylo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quad (4-lane) cross-lane helpers on DPP quad_perm — the renorm byte-emit compaction of
+// ans_fold.hpp:100-112 / :216-228: 4 interleaved states share one byte cursor.
+// ---------------------------------------------------------------------------------------------
+#define ANSX_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+
+template <int CTRL> ANSX_D u32 quad_perm(u32 v)
+{
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+
+// inclusive prefix sum over the 4 lanes of a quad; *total receives the quad sum
+ANSX_D u32 quad_incl_scan(u32 c, u32 ql, u32* total)
+{
+    u32 a = quad_perm<ANSX_QP(0, 0, 1, 2)>(c);
+    u32 s1 = c + ((ql >= 1) ? a : 0u);
+    u32 b = quad_perm<ANSX_QP(0, 0, 0, 1)>(s1);
+    u32 s2 = s1 + ((ql >= 2) ? b : 0u);
+    *total = quad_perm<ANSX_QP(3, 3, 3, 3)>(s2);
+    return s2;
+}
+
+// byte-granular global accesses.  gfx950 global memory supports unaligned dword/dwordx2
+// accesses (HSA unaligned access mode); the packed structs make hipcc emit single
+// global_load/store instructions with align 1.
+struct __attribute__((packed)) ansx_u64_u { u64 v; };
+struct __attribute__((packed)) ansx_u32_u { u32 v; };
+struct __attribute__((packed)) ansx_u16_u { u16 v; };
+ANSX_D u64 ld_u64_unaligned(const u8* p) { return ((const ansx_u64_u*)p)->v; }
+ANSX_D u32 ld_u32_unaligned(const u8* p) { return ((const ansx_u32_u*)p)->v; }
+ANSX_D void st_u64_unaligned(u8* p, u64 v) { ((ansx_u64_u*)p)->v = v; }
+ANSX_D void st_u32_unaligned(u8* p, u32 v) { ((ansx_u32_u*)p)->v = v; }
+ANSX_D void st_u16_unaligned(u8* p, u16 v) { ((ansx_u16_u*)p)->v = v; }
+
+// ---------------------------------------------------------------------------------------------
+// Block geometry shared by host and kernels
+// ---------------------------------------------------------------------------------------------
+struct ansx_geo {
+    u64 n;           // total ints
+    u32 block_ints;  // ints per block (last block may be shorter)
+    u32 nblocks;
+    u32 ckpt;        // restart interval in ints (0 = none)
+    u32 nckf;        // restart points stored per block (stride)
+    u32 f;           // fidelity
+    u32 kind;        // 0 fold, 1 rfold
+};
+
+ANSX_HD u32 geo_block_n(const ansx_geo& g, u32 b)
+{
+    u64 start = (u64)b * g.block_ints;
+    u64 rem = g.n - start;
+    return (u32)(rem < g.block_ints ? rem : g.block_ints);
+}
+// decoder segments of a block with nb ints
+ANSX_HD u32 geo_nseg(u32 nb, u32 ckpt)
+{
+    u32 nfull = nb - (nb & 3u);
+    if (ckpt == 0 || nfull == 0) return 1;
+    return (nfull + ckpt - 1) / ckpt;
+}

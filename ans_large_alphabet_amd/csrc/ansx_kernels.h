@@ -1,0 +1,972 @@
+// ansx device kernels (gfx950).  One block = one independent reference encode() call
+// (SURVEY F1); kernels are organised so that lanes = ANS states:
+//
+//   encode:  K1 k_fold_hist       per-block folded-symbol histogram in LDS        ans_fold.hpp:70-78
+//            K2 k_sort_entropy    (freq,sym) sort + entropy H                     ans_util.hpp:114-124, util.hpp:271-282
+//               k_scale_attempts  one lane per (block, frame size) recurrence      ans_util.hpp:77-95
+//               k_select_model    cross entropy + stop rule + encoder table        ans_util.hpp:127-153, ans_fold.hpp:82-91
+//            K3 k_write_prelude   vbyte + log2 M + parallel interpolative coder    ans_util.hpp:46-63, interp.hpp:28-79
+//            K5 k_encode          quad of lanes per block, 4 interleaved states    ans_fold.hpp:100-120,249-278
+//            K6 k_scan_sizes / k_compact / k_write_header   container assembly
+//   decode:  K8 k_decode          prelude parse + LDS tables + quad per segment    ans_fold.hpp:179-228,283-311
+#pragma once
+
+#include "ansx_dev.h"
+
+// ------------------------------------------------------------------------------------------
+// per-block metadata (device)
+// ------------------------------------------------------------------------------------------
+struct ansx_blk {
+    u32 n;              // ints in this block (sum of histogram)
+    u32 max_sym;        // largest folded symbol
+    u32 sigma;          // number of distinct folded symbols
+    u32 m0_log2;        // log2 of the first frame size tried
+    double H;           // entropy (bits/symbol)
+    double thr;         // H * 1.001
+    u32 resolved;       // model chosen
+    int prev;           // last successful-but-rejected attempt (global attempt index), -1 = none
+    u32 logM;           // log2 of the chosen frame size
+    u32 status;         // 0 ok, else ansx_status
+    u32 prelude_bytes;  // header + prelude = offset of the first payload byte
+    u32 stream_bytes;   // total bytes of this block's reference stream
+    u32 hdr_bytes;      // rfold header bytes (4 or 4+4T), 0 for fold
+    u32 flag;           // rfold reorder flag
+};
+
+// encoder table entry (ans_fold.hpp:30-34 enc_entry_fold, plus the reciprocal used for the
+// exact state/freq division)
+struct __attribute__((aligned(16))) ansx_enc_entry {
+    u32 base;
+    u32 freq;
+    double rcp;
+};
+
+enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3 };
+enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
+
+// ------------------------------------------------------------------------------------------
+// K1: folded-symbol histogram.  One workgroup per chunk of a block; LDS bins; coalesced 16 B
+// loads.  Replaces the first pass of ans_fold_encode<f>::create (ans_fold.hpp:74-78).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
+    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, ansx_blk* __restrict__ blk,
+    u32* __restrict__ gflags, u32 value_limit)
+{
+    extern __shared__ u32 lds_hist[];
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x / cpb, c = blockIdx.x % cpb;
+    const u32 nb = geo_block_n(g, b);
+    const u64 start = (u64)c * chunk;
+    if (start >= nb) return;
+    const u32 len = (u32)((nb - start) < chunk ? (nb - start) : chunk);
+    const u32* src = in + (u64)b * g.block_ints + start;
+    for (u32 s = tid; s < NSP; s += 256) lds_hist[s] = 0;
+    __syncthreads();
+    const u32 f = g.f;
+    u32 lmax = 0, bad = 0;
+    auto take = [&](u32 x) {
+        bad |= (x >= value_limit) ? 1u : 0u;
+        u32 k = fold_nbytes(f, x);
+        u32 s = fold_sym(f, x, k);
+        atomicAdd(&lds_hist[s], 1u);
+        lmax = s > lmax ? s : lmax;
+    };
+    u32 done = 0;
+    if ((((uintptr_t)src) & 15u) == 0) {
+        const uint4* v4 = (const uint4*)src;
+        const u32 nvec = len >> 2;
+        for (u32 v = tid; v < nvec; v += 256) {
+            uint4 q = v4[v];
+            take(q.x);
+            take(q.y);
+            take(q.z);
+            take(q.w);
+        }
+        done = nvec << 2;
+    }
+    for (u32 i = done + tid; i < len; i += 256) take(src[i]);
+    __syncthreads();
+    u32* h = hist + (u64)b * NSP;
+    if (cpb == 1) {
+        for (u32 s = tid; s < NSP; s += 256) h[s] = lds_hist[s];
+    } else {
+        for (u32 s = tid; s < NSP; s += 256) {
+            u32 v = lds_hist[s];
+            if (v) atomicAdd(&h[s], v);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        u32 t = __shfl_xor(lmax, o);
+        lmax = t > lmax ? t : lmax;
+        bad |= __shfl_xor(bad, o);
+    }
+    if ((tid & 63) == 0) {
+        atomicMax(&blk[b].max_sym, lmax);
+        if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a: sort the non-zero (freq, sym) pairs ascending (ans_util.hpp:114-122) with an LDS bitonic
+// network, and evaluate the entropy H in index order (util.hpp:271-282): the p*log2(p) terms
+// are computed lane-parallel, the sum is taken serially so that its rounding matches a scalar
+// left-to-right accumulation.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sort_entropy(ansx_geo g, u32 NSP,
+    const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
+    ansx_blk* __restrict__ blk)
+{
+    extern __shared__ u64 lds64[];
+    __shared__ u32 sh_sigma;
+    __shared__ unsigned long long sh_total;
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const u32 ns = blk[b].max_sym + 1;
+    u32 N2 = 2;
+    while (N2 < ns) N2 <<= 1;
+    u64* keys = lds64;
+    double* terms = (double*)(lds64 + N2);
+    const u32* h = hist + (u64)b * NSP;
+    if (tid == 0) {
+        sh_sigma = 0;
+        sh_total = 0;
+    }
+    __syncthreads();
+    u32 lsig = 0;
+    u64 ltot = 0;
+    for (u32 s = tid; s < N2; s += 256) {
+        u32 fr = s < ns ? h[s] : 0u;
+        keys[s] = fr ? (((u64)fr << 16) | s) : ~0ull;
+        lsig += fr ? 1u : 0u;
+        ltot += fr;
+    }
+    atomicAdd(&sh_sigma, lsig);
+    atomicAdd(&sh_total, (unsigned long long)ltot);
+    __syncthreads();
+    for (u32 k = 2; k <= N2; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < N2; i += 256) {
+                u32 ixj = i ^ j;
+                if (ixj > i) {
+                    bool asc = (i & k) == 0;
+                    u64 x = keys[i], y = keys[ixj];
+                    if ((x > y) == asc) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const u32 sigma = sh_sigma;
+    const u64 total = sh_total;
+    u32* oF = sortF + (u64)b * NSP;
+    u16* oS = sortSym + (u64)b * NSP;
+    for (u32 j = tid; j < sigma; j += 256) {
+        u64 kx = keys[j];
+        oF[j] = (u32)(kx >> 16);
+        oS[j] = (u16)(kx & 0xFFFFu);
+    }
+    // entropy, util.hpp:271-282
+    const double nd = (double)total;
+    double acc = 0.0;
+    for (u32 base = 0; base < ns; base += 1024) {
+        __syncthreads();
+        for (u32 u = tid; u < 1024; u += 256) {
+            u32 i = base + u;
+            u32 fr = i < ns ? h[i] : 0u;
+            double t = 1.0;  // marker: absent (real terms are <= 0)
+            if (fr) {
+                double p = (double)fr / nd;
+                t = p * ansx_log2_portable(p);
+            }
+            terms[u] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 lim = ns - base < 1024 ? ns - base : 1024;
+            for (u32 u = 0; u < lim; u++) {
+                double t = terms[u];
+                if (t <= 0.0) acc = acc + t;
+            }
+        }
+    }
+    if (tid == 0) {
+        double H = -acc;
+        double approx = 1.0 + (double)1 / (double)1000;  // ans_util.hpp:124
+        u32 m0 = 0;  // ans_util.hpp:109-112
+        if (sigma != 0 && (sigma & (sigma - 1)) == 0) m0 = 31 - __clz(sigma);
+        else m0 = sigma == 0 ? 0 : (32 - __clz(sigma));
+        ansx_blk* B = &blk[b];
+        B->n = (u32)total;
+        B->sigma = sigma;
+        B->m0_log2 = m0;
+        B->H = H;
+        B->thr = H * approx;
+        B->resolved = 0;
+        B->prev = -1;
+        B->status = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b: scale_freqs (ans_util.hpp:77-95).  The recurrence over symbols is serial (each S
+// depends on the remaining frame), but different frame sizes M0*2^t are independent: one lane
+// per (block, t).  Doubles are evaluated exactly as written (no contraction).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32 batch,
+    const u32* __restrict__ sortF, const u16* __restrict__ sortSym, const ansx_blk* __restrict__ blk,
+    u16* __restrict__ attS, u32* __restrict__ attMeta)
+{
+    const u32 gid = blockIdx.x * 256 + threadIdx.x;
+    const u32 b = gid / ANSX_ATTEMPTS, t = gid % ANSX_ATTEMPTS;
+    if (b >= g.nblocks) return;
+    const ansx_blk B = blk[b];
+    if (B.resolved) return;
+    const u32 T = batch * ANSX_ATTEMPTS + t;
+    const u32 sh = B.m0_log2 + T;
+    u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 2;
+    if (sh > 31) {  // frame sizes beyond 2^31 are unreachable for valid inputs
+        meta[0] = 0;
+        meta[1] = 0;
+        return;
+    }
+    i64 M = (i64)1 << sh;
+    u64 fs = B.n;
+    const u32* F = sortF + (u64)b * NSP;
+    const u16* Sy = sortSym + (u64)b * NSP;
+    u16* S = attS + ((u64)b * ANSX_ATTEMPTS + t) * NSP;
+    u32 maxS = 0;
+    const u32 sigma = B.sigma;
+    for (u32 j = 0; j < sigma; j++) {  // evaluated as written: TU is built with -ffp-contract=off
+        u32 fr = F[j];
+        u32 sym = Sy[j];
+        double aratio = (double)M / (double)fs;
+        double v = aratio * (double)fr;
+        v = 0.5 + v;
+        u32 s = (u32)v;
+        if (s == 0) s = 1;
+        S[sym] = (u16)(s > 65535u ? 65535u : s);
+        maxS = s > maxS ? s : maxS;
+        M -= s;
+        fs -= fr;
+        if (M < 0) break;
+    }
+    meta[0] = (M == 0) ? 1u : 0u;
+    meta[1] = maxS;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2c: stop rule of adjust_freqs (ans_util.hpp:127-153) + cross entropy (util.hpp:284-298)
+// + encoder table (ans_fold.hpp:82-91).  One wave per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 batch,
+    const u32* __restrict__ hist, const u16* __restrict__ attS, const u32* __restrict__ attMeta,
+    u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
+    u32* __restrict__ gflags, u32 last_batch)
+{
+    __shared__ double terms[1024];
+    __shared__ int sh_flag;
+    __shared__ u32 sh_part[64];
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    ansx_blk* B = &blk[b];
+    if (B->resolved) return;
+    const u32 ns = B->max_sym + 1;
+    const u32* h = hist + (u64)b * NSP;
+    const double nd = (double)(int)B->n;  // util.hpp:288: accumulate into int
+    const double thr = B->thr;
+    int prev = B->prev;
+    int chosen = -2;
+    for (u32 t = 0; t < ANSX_ATTEMPTS; t++) {
+        const u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 2;
+        if (!meta[0]) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
+        const u32 T = batch * ANSX_ATTEMPTS + t;
+        if (meta[1] >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
+            chosen = prev;
+            break;
+        }
+        const u16* S = attS + ((u64)b * ANSX_ATTEMPTS + t) * NSP;
+        const double md = (double)(int)(1u << (B->m0_log2 + T));
+        double acc = 0.0;
+        for (u32 base = 0; base < ns; base += 1024) {
+            __syncthreads();
+            for (u32 u = lane; u < 1024; u += 64) {
+                u32 i = base + u;
+                u32 fr = i < ns ? h[i] : 0u;
+                double tm = 1.0;
+                if (fr) {
+                    double p = (double)fr / nd;
+                    double q = (double)S[i] / md;
+                    tm = p * ansx_log2_portable(q);
+                }
+                terms[u] = tm;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                u32 lim = ns - base < 1024 ? ns - base : 1024;
+                for (u32 u = 0; u < lim; u++) {
+                    double tm = terms[u];
+                    if (tm <= 0.0) acc = acc + tm;
+                }
+            }
+        }
+        if (lane == 0) sh_flag = ((-acc) < thr) ? 1 : 0;  // ans_util.hpp:149
+        __syncthreads();
+        int ok = sh_flag;
+        __syncthreads();
+        if (ok) {
+            chosen = (int)T;
+            break;
+        }
+        prev = (int)T;
+    }
+    if (chosen == -2) {
+        // still undecided after this batch: remember the last rejected success
+        if (prev >= (int)(batch * ANSX_ATTEMPTS)) {
+            const u16* S = attS + ((u64)b * ANSX_ATTEMPTS + (prev - batch * ANSX_ATTEMPTS)) * NSP;
+            u16* P = prevS + (u64)b * NSP;
+            for (u32 s = lane; s < ns; s += 64) P[s] = S[s];
+        }
+        if (lane == 0) {
+            B->prev = prev;
+            if (last_batch) {
+                B->resolved = 1;
+                B->status = 7;  // ANSX_ERR_MODEL
+                atomicOr(&gflags[ANSX_G_ERR], 1u << 7);
+            }
+        }
+        return;
+    }
+    if (chosen < 0) {  // "prev" is the all-zero vector: reference's degenerate exit
+        if (lane == 0) {
+            B->resolved = 1;
+            B->status = 7;
+            B->logM = 0;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << 7);
+        }
+        return;
+    }
+    const u16* S = (chosen >= (int)(batch * ANSX_ATTEMPTS))
+        ? attS + ((u64)b * ANSX_ATTEMPTS + (chosen - batch * ANSX_ATTEMPTS)) * NSP
+        : prevS + (u64)b * NSP;
+    // exclusive scan of the chosen frequencies -> encoder table (ans_fold.hpp:82-91)
+    const u32 per = (ns + 63) / 64;
+    const u32 lo = lane * per, hi = (lo + per) < ns ? (lo + per) : ns;
+    u32 sum = 0;
+    for (u32 s = lo; s < hi; s++) sum += h[s] ? (u32)S[s] : 0u;
+    sh_part[lane] = sum;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 l = 0; l < lane; l++) run += sh_part[l];
+    ansx_enc_entry* tab = table + (u64)b * NSP;
+    for (u32 s = lo; s < hi; s++) {
+        u32 fr = h[s] ? (u32)S[s] : 0u;
+        ansx_enc_entry e;
+        e.base = run;
+        e.freq = fr;
+        e.rcp = fr ? 1.0 / (double)fr : 0.0;
+        tab[s] = e;
+        run += fr;
+    }
+    if (lane == 0) {
+        u32 logM = B->m0_log2 + (u32)chosen;
+        B->logM = logM;
+        B->resolved = 1;
+        atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
+        atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: prelude writer (ans_util.hpp:46-63).  The binary interpolative code (interp.hpp:65-79)
+// is a pre-order walk of a balanced tree whose node contexts depend only on input values, so
+// every item's codeword is computed independently: lane i finds its node by descending from
+// the root (rank = pre-order position), codeword lengths are prefix-summed in rank order, and
+// codewords are OR-ed into an LDS bit buffer (LSB-first u32 words, bits.hpp:84-105).  Padding
+// bits of the last word are written as zero (canonical form).
+// ------------------------------------------------------------------------------------------
+struct ansx_code {
+    u32 code, len, rank;
+};
+
+__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, u64 u, u32 i)
+{
+    u32 a = 0, n = ns, rank = 0;
+    u32 h, mid;
+    for (;;) {
+        h = (n + 1) >> 1;
+        mid = a + h - 1;
+        if (i == mid) break;
+        if (i < mid) {
+            n = h - 1;
+            rank += 1;
+        } else {
+            rank += h;
+            a += h;
+            n -= h;
+        }
+    }
+    const u64 n1 = h - 1, n2 = n - h;
+    const u64 low = (a == 0) ? 1ull : (u64)inc[a - 1] + 2ull;          // parent v + 1
+    const u64 high = (a + n == ns) ? (u + 1ull) : (u64)inc[a + n];     // parent v - 1
+    const u64 v = (u64)inc[mid] + 1ull;                                // interp.hpp:73
+    u64 val = v - low - n1 + 1ull;
+    const u64 U = high - n2 - low - n1 + 1ull;
+    ansx_code c;
+    c.rank = rank;
+    if (U == 1) {  // interp.hpp:31-32
+        c.code = 0;
+        c.len = 0;
+        return c;
+    }
+    const u32 bb = 64 - __clzll((unsigned long long)(U - 1));  // hi(U-1)+1
+    const u64 d = 2ull * U - (1ull << bb);
+    val = val + (U - (d >> 1));
+    if (val > U) val -= U;
+    const u64 m = (1ull << bb) - U;
+    if (val <= m) {
+        c.code = (u32)(val - 1ull);
+        c.len = bb - 1;
+    } else {
+        val += m;
+        c.code = (u32)(((val - 1ull) >> 1) | (((val - 1ull) & 1ull) << (bb - 1)));
+        c.len = bb;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
+    const ansx_enc_entry* __restrict__ table, u32* __restrict__ incbuf, ansx_blk* __restrict__ blk,
+    u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
+{
+    extern __shared__ u32 lds32[];
+    __shared__ u32 sh_part[256];
+    __shared__ u32 sh_total;
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    ansx_blk* B = &blk[b];
+    if (B->status) {
+        if (tid == 0) {
+            B->prelude_bytes = 0;
+        }
+        return;
+    }
+    const u32 ns = B->max_sym + 1;
+    const u32 logM = B->logM;
+    u32* off = lds32;         // [ns]
+    u32* bits = lds32 + NSP;  // bit buffer
+    u32* inc = incbuf + (u64)b * NSP;
+    const ansx_enc_entry* tab = table + (u64)b * NSP;
+    for (u32 s = tid; s < ns; s += 256) {
+        ansx_enc_entry e = tab[s];
+        inc[s] = e.base + e.freq + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+    }
+    __threadfence_block();
+    __syncthreads();
+    const u64 u = ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
+    for (u32 i = tid; i < ns; i += 256) {
+        ansx_code c = interp_item(inc, ns, u, i);
+        off[c.rank] = c.len;
+    }
+    __syncthreads();
+    // exclusive scan of off[0..ns)
+    const u32 per = (ns + 255) / 256;
+    const u32 lo = tid * per, hi = (lo + per) < ns ? (lo + per) : ns;
+    u32 sum = 0;
+    for (u32 s = lo; s < hi; s++) sum += off[s];
+    sh_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (u32 l = 0; l < 256; l++) {
+            u32 t = sh_part[l];
+            sh_part[l] = run;
+            run += t;
+        }
+        sh_total = run;
+    }
+    __syncthreads();
+    u32 run = sh_part[tid];
+    for (u32 s = lo; s < hi; s++) {
+        u32 t = off[s];
+        off[s] = run;
+        run += t;
+    }
+    const u32 total_bits = sh_total;
+    const u32 nwords = (total_bits + 31) >> 5;
+    for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < ns; i += 256) {
+        ansx_code c = interp_item(inc, ns, u, i);
+        if (c.len) {
+            u32 o = off[c.rank];
+            u32 w = o >> 5, sh = o & 31;
+            atomicOr(&bits[w], c.code << sh);
+            if (sh + c.len > 32) atomicOr(&bits[w + 1], c.code >> (32 - sh));
+        }
+    }
+    __syncthreads();
+    u8* out = scratch + (u64)b * scr_stride;
+    u32 p = 0;
+    if (g.kind == 1) {  // ans_reorder_fold.hpp:132-154
+        const u32 T = fold_T(g.f);
+        const u32 flag = B->flag;
+        if (tid == 0) st_u32_unaligned(out, flag);
+        p = 4;
+        if (flag) {
+            const u32* mf = mostfreq + (u64)b * T;
+            for (u32 i = tid; i < T; i += 256) st_u32_unaligned(out + 4 + 4 * (u64)i, mf[i]);
+            p += 4 * T;
+        }
+    }
+    const u32 hdr = p;
+    // vbyte(max_sym) (vbyte.hpp:57-80) + log2(M) byte (ans_util.hpp:51)
+    u32 ms = ns - 1;
+    u32 vb = 1;
+    for (u32 t = ms; t >= 128; t >>= 7) vb++;
+    if (tid == 0) {
+        u32 t = ms;
+        u32 q = p;
+        while (t >= 128) {
+            out[q++] = (u8)((t & 127) | 128);
+            t >>= 7;
+        }
+        out[q++] = (u8)(t & 127);
+        out[q] = (u8)logM;
+    }
+    p += vb + 1;
+    const u32 nbytes = nwords * 4;
+    for (u32 j = tid; j < nbytes; j += 256) out[p + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
+    if (tid == 0) {
+        B->hdr_bytes = hdr;
+        B->prelude_bytes = p + nbytes;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: the 4-state rANS encoder (ans_fold.hpp:100-120, 249-278).  A quad of lanes owns one
+// block; lane q carries state q and encodes in[4g+3-q] of every group g, walking the block
+// backwards.  Bytes emitted by the four lanes of a step (k exception bytes, then the 32-bit
+// renormalisation word) are laid out by a quad prefix sum over DPP.  state/freq is evaluated
+// exactly through the reciprocal stored in the table plus a +-1 correction.
+// ------------------------------------------------------------------------------------------
+struct enc_lane {
+    u64 st;
+    u32 p;  // byte cursor relative to the block's stream start (uniform within the quad)
+};
+
+__device__ __forceinline__ void enc_step(enc_lane& L, u32 x, bool active, u32 ql, u32 f, u32 logM,
+    const ansx_enc_entry* __restrict__ tab, u8* __restrict__ out)
+{
+    const u32 k = fold_nbytes(f, x);
+    const u32 sym = fold_sym(f, x, k);
+    const u32 eb = x & ((1u << (8 * k)) - 1u);
+    const ansx_enc_entry e = tab[sym];
+    u64 st = L.st;
+    // renormalise: state >= K*RADIX*freq  <=>  (state >> 36) >= freq   (ans_fold.hpp:105-110)
+    const bool rn = active && ((u32)(st >> 36) >= e.freq);
+    const u32 w = (u32)st;
+    if (rn) st >>= 32;
+    // exact q = st / freq, r = st % freq; st < 2^36 * freq <= 2^52 (ans_fold.hpp:111)
+    double qd = (double)st * e.rcp;
+    u64 q = (u64)qd;
+    i64 r = (i64)st - (i64)(q * (u64)e.freq);
+    if (r < 0) {
+        q -= 1;
+        r += e.freq;
+    } else if (r >= (i64)e.freq) {
+        q += 1;
+        r -= e.freq;
+    }
+    st = (q << logM) + (u64)r + (u64)e.base;
+    if (active) L.st = st;
+    const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
+    u32 total;
+    const u32 incl = quad_incl_scan(c, ql, &total);
+    u8* a = out + L.p + (incl - c);
+    if (active) {
+        if (k == 1) a[0] = (u8)eb;
+        if (k >= 2) st_u16_unaligned(a, (u16)eb);
+        if (k == 3) a[2] = (u8)(eb >> 16);
+        if (rn) st_u32_unaligned(a + k, w);
+    }
+    L.p += total;
+}
+
+__global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
+    const ansx_enc_entry* __restrict__ table, ansx_blk* __restrict__ blk, u8* __restrict__ scratch,
+    u64 scr_stride, u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
+{
+    const u32 gt = blockIdx.x * 64 + threadIdx.x;
+    const u32 b = gt >> 2, ql = gt & 3;
+    if (b >= g.nblocks) return;
+    ansx_blk* B = &blk[b];
+    if (B->status) {
+        if (ql == 0) B->stream_bytes = 0;
+        return;
+    }
+    const u32 nb = geo_block_n(g, b);
+    const u32* src = in + (u64)b * g.block_ints;
+    const ansx_enc_entry* tab = table + (u64)b * NSP;
+    u8* out = scratch + (u64)b * scr_stride;
+    const u32 f = g.f, logM = B->logM;
+    const u64 Lb = (u64)16 << logM;
+    enc_lane L;
+    L.st = Lb;
+    L.p = B->prelude_bytes;
+    const u32 r = nb & 3;
+    // tail symbols all go to state 0 (ans_fold.hpp:257-261)
+    for (u32 t = 0; t < r; t++) {
+        u32 x = src[nb - 1 - t];
+        enc_step(L, x, ql == 0, ql, f, logM, tab, out);
+    }
+    // groups of four, backwards (ans_fold.hpp:262-272): in[4g+3-q] -> state q
+    const u32 G = nb >> 2;
+    const u32 cg = g.ckpt >> 2;  // groups per restart interval (0 = none)
+    u32 ck_seg = (cg && G) ? (G - 1) / cg : 0;  // next restart point to record: segment index
+    u32 ck_g = ck_seg * cg;                     // ... and its group index
+    for (u32 gi = G; gi > 0; gi--) {
+        const u32 gidx = gi - 1;
+        u32 x = src[4 * gidx + 3 - ql];
+        enc_step(L, x, true, ql, f, logM, tab, out);
+        // every symbol with index >= 4*gidx is now encoded: decoder restart point of segment
+        // ck_seg (the decoder of that segment starts with exactly these states and cursor)
+        if (ck_seg && gidx == ck_g) {
+            const u64 idx = (u64)b * g.nckf + (ck_seg - 1);
+            ckpt_state[idx * 4 + ql] = L.st;
+            if (ql == 0) ckpt_off[idx] = L.p;
+            ck_seg--;
+            ck_g -= cg;
+        }
+    }
+    // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
+    st_u64_unaligned(out + L.p + 8 * ql, L.st - Lb);
+    if (ql == 0) B->stream_bytes = L.p + 32;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: container assembly.  Exclusive scan of the block stream sizes, then a gather copy of
+// every block's bytes from its worst-case-strided scratch slot to its final offset.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_sizes(ansx_geo g, const ansx_blk* __restrict__ blk,
+    u64* __restrict__ block_off, u64* __restrict__ result, u64 payload_off, u64 capacity,
+    u32* __restrict__ gflags)
+{
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 NB = g.nblocks;
+    const u32 per = (NB + 1023) / 1024;
+    const u32 lo = tid * per, hi = (lo + per) < NB ? (lo + per) : NB;
+    u64 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += blk[i].stream_bytes;
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        u64 run = 0;
+        for (u32 l = 0; l < 1024; l++) {
+            u64 t = part[l];
+            part[l] = run;
+            run += t;
+        }
+        block_off[NB] = run;
+        result[0] = run;  // payload bytes
+        if (payload_off + run > capacity) atomicOr(&gflags[ANSX_G_ERR], 1u << 2 /* CAPACITY */);
+    }
+    __syncthreads();
+    u64 run = part[tid];
+    for (u32 i = lo; i < hi; i++) {
+        block_off[i] = run;
+        run += blk[i].stream_bytes;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact(ansx_geo g, const ansx_blk* __restrict__ blk,
+    const u64* __restrict__ block_off, const u8* __restrict__ scratch, u64 scr_stride,
+    u8* __restrict__ payload, const u32* __restrict__ gflags)
+{
+    if (gflags[ANSX_G_ERR]) return;  // capacity / domain / model error: nothing is copied
+    const u32 b = blockIdx.x;
+    const u32 tid = threadIdx.x;
+    const u32 size = blk[b].stream_bytes;
+    const u8* src = scratch + (u64)b * scr_stride;
+    u8* dst = payload + block_off[b];
+    // head: bytes until dst is 4-byte aligned
+    u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (head > size) head = size;
+    if (tid < head) dst[tid] = src[tid];
+    const u32 nd = (size - head) >> 2;
+    u32* d4 = (u32*)(dst + head);
+    const u8* s1 = src + head;
+    for (u32 j = tid; j < nd; j += 256) d4[j] = ld_u32_unaligned(s1 + 4 * (u64)j);
+    const u32 done = head + 4 * nd;
+    if (done + tid < size) dst[done + tid] = src[done + tid];
+}
+
+__global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __restrict__ gflags,
+    const u64* __restrict__ result, u64 payload_off)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // ansx_container_header, little endian (include/ansx.h)
+    const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
+    for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
+    u32* w = (u32*)(out + 8);
+    w[0] = g.kind;
+    w[1] = g.f;
+    *(u64*)(out + 16) = g.n;
+    w = (u32*)(out + 24);
+    w[0] = g.block_ints;
+    w[1] = g.ckpt;
+    w[2] = g.nblocks;
+    w[3] = gflags[ANSX_G_MAXLOGM];
+    w[4] = gflags[ANSX_G_MAXNSYMS];
+    w[5] = g.nckf;
+    *(u64*)(out + 48) = result[0];
+    *(u64*)(out + 56) = payload_off;
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: decoder (ans_fold.hpp:179-228, 283-311).  One workgroup per block:
+//   1. lane 0 parses the prelude (vbyte, log2 M, interpolative code — inherently serial bit
+//      parsing, ans_util.hpp:25-42, interp.hpp:47-63,81-97) into the cumulative table,
+//   2. all lanes build the slot -> symbol table (the reference's table[M], ans_fold.hpp:190-204,
+//      in 2 bytes per slot),
+//   3. each quad of lanes decodes one segment forward from its restart point: lane q carries
+//      state 3-q and produces out[4g+q]; bytes consumed per step (renorm word, then exception
+//      bytes) are located by a quad prefix sum, one unaligned 8-byte load per lane and step.
+// Tables live in LDS (LDS_TAB) or, for very large frames, in a global workspace.
+// ------------------------------------------------------------------------------------------
+struct dec_tables {
+    u32* cum;   // [ns+1]
+    u16* s2s;   // [M]
+    u32* mf;    // rfold: most-frequent table [T] (LDS copy) or nullptr
+};
+
+template <bool RFOLD>
+__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u32 f, u32 logM,
+    u32 mask, u64 Lb, const u32* cum, const u16* s2s, const u32* mf, u32 rflag,
+    const u8* __restrict__ stream)
+{
+    const u32 slot = (u32)st & mask;
+    const u32 sym = s2s[slot];
+    const u32 c0 = cum[sym], c1 = cum[sym + 1];
+    const u32 fr = c1 - c0;
+    u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - c0);  // ans_fold.hpp:218-220
+    const bool rn = active && (ns_ < Lb);
+    const u32 k = unfold_nbytes(f, sym);
+    const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
+    u32 total;
+    const u32 incl = quad_incl_scan(c, ql, &total);
+    int myp = p - (int)(incl - c);
+    myp = myp < 0 ? 0 : myp;
+    const u64 v = ld_u64_unaligned(stream + myp - 8);
+    if (rn) ns_ = (ns_ << 32) | (v >> 32);  // ans_fold.hpp:221-225
+    if (active) st = ns_;
+    // exception bytes sit just below the renorm word (ans_fold.hpp:135-147)
+    const u32 e = c ? ((u32)(v >> (64 - 8 * c)) & ((1u << (8 * k)) - 1u)) : 0u;
+    u32 val = unfold_value(f, sym, k) + e;
+    if (RFOLD) {
+        const u32 T = fold_T(f);
+        if (rflag) val = (sym < T) ? mf[sym] : (val - T);  // ans_reorder_fold.hpp:207-219,300-301
+    }
+    p -= (int)total;
+    return val;
+}
+
+template <bool LDS_TAB, bool RFOLD>
+__global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
+    u32 max_ns, u16* __restrict__ g_s2s, u32* __restrict__ g_cum, u32* __restrict__ gflags)
+{
+    extern __shared__ u8 smem[];
+    __shared__ u32 sh_hdr[8];  // ns, logM, interp byte offset, flag, error
+    __shared__ u32 stk[4 * 20];
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 b = blockIdx.x;
+    const u32 nb = geo_block_n(g, b);
+    const u64 boff = block_off[b];
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const u32 f = g.f;
+    const u32 T = fold_T(f);
+    u32* cum;
+    u16* s2s;
+    u32* mfl = nullptr;
+    if (LDS_TAB) {
+        cum = (u32*)smem;
+        u32 cb = ((max_ns + 2) * 4 + 15) & ~15u;
+        s2s = (u16*)(smem + cb);
+        if (RFOLD) mfl = (u32*)(smem + cb + (((u64)maxM * 2 + 15) & ~15ull));
+    } else {
+        cum = g_cum + (u64)b * (NSP + 8);
+        s2s = g_s2s + (u64)b * maxM;
+        if (RFOLD) mfl = (u32*)smem;
+    }
+    // ---- 1. prelude parse by lane 0
+    if (tid == 0) {
+        u32 err = 0;
+        u32 pos = 0, flag = 0;
+        if (RFOLD) {  // ans_reorder_fold.hpp:238-254
+            flag = ld_u32_unaligned(stream);
+            pos = 4 + (flag == 1 ? 4 * T : 0);
+            if (flag > 1) err = 1;
+        }
+        // vbyte (vbyte.hpp:82-95)
+        u32 ms = 0, shv = 0;
+        for (int i = 0; i < 5; i++) {
+            u8 cbyte = stream[pos++];
+            ms += (u32)(cbyte & 127) << shv;
+            if (!(cbyte & 128)) break;
+            shv += 7;
+        }
+        const u32 logM = stream[pos++];
+        const u32 ns = ms + 1;
+        if (ns > max_ns || ns > NSP || logM > 31 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
+        sh_hdr[0] = ns;
+        sh_hdr[1] = logM;
+        sh_hdr[3] = flag;
+        if (!err) {
+            // interpolative decode, iterative pre-order walk (interp.hpp:81-97)
+            const u8* bp = stream + pos;
+            u64 bitpos = 0;
+            const u64 maxbits = ((u64)sbytes - pos) * 8;
+            auto getbits = [&](u32 nbits) -> u32 {
+                if (nbits == 0) return 0u;
+                u64 byte = bitpos >> 3;
+                u32 sh = (u32)(bitpos & 7);
+                u64 wv = ld_u64_unaligned(bp + byte);
+                bitpos += nbits;
+                return (u32)((wv >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
+            };
+            const u64 u = ((u64)1 << logM) + ns + 1;
+            u32 sp = 0;
+            stk[0] = 0;
+            stk[1] = ns;
+            // low/high are < 2^33: store as two words each? they fit u32 when M <= 2^31 - ns
+            stk[2] = 1;
+            stk[3] = (u32)(u + 1);
+            sp = 1;
+            while (sp > 0 && !err) {
+                sp--;
+                u32 a = stk[4 * sp], n = stk[4 * sp + 1];
+                u64 low = stk[4 * sp + 2], high = stk[4 * sp + 3];
+                while (n > 0) {
+                    const u32 h = (n + 1) >> 1;
+                    const u64 n1 = h - 1, n2 = n - h;
+                    const u64 U = high - n2 - low - n1 + 1;
+                    if ((i64)U < 1 || bitpos > maxbits) {
+                        err = 1;
+                        break;
+                    }
+                    // read_center_mid (interp.hpp:47-63)
+                    u64 val = 1;
+                    const u32 bb = (U == 1) ? 0u : (64 - __clzll((unsigned long long)(U - 1)));
+                    const u64 d = 2ull * U - (1ull << bb);
+                    if (U != 1) {
+                        const u64 m = (1ull << bb) - U;
+                        val = (u64)getbits(bb - 1) + 1;
+                        if (val > m) val = (2ull * val + getbits(1)) - m - 1ull;
+                    }
+                    val = val + (d >> 1);
+                    if (val > U) val -= U;
+                    const u64 v = low + n1 - 1ull + val;
+                    cum[a + h] = (u32)(v - 1);  // inc[a+h-1], stored one slot up (see below)
+                    if (n2) {
+                        stk[4 * sp] = a + h;
+                        stk[4 * sp + 1] = (u32)n2;
+                        stk[4 * sp + 2] = (u32)(v + 1);
+                        stk[4 * sp + 3] = (u32)high;
+                        sp++;
+                    }
+                    n = (u32)n1;
+                    high = v - 1;
+                }
+            }
+        }
+        sh_hdr[4] = err;
+        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (sh_hdr[4]) return;
+    const u32 ns = sh_hdr[0], logM = sh_hdr[1], rflag = sh_hdr[3];
+    const u32 M = 1u << logM;
+    // inc[s] = sum_{t<=s} nfreq[t] + s  (ans_util.hpp:33-41)  ->  cum[s+1] = inc[s] - s
+    for (u32 s = tid; s < ns; s += nt) cum[s + 1] = cum[s + 1] - s;
+    if (tid == 0) cum[0] = 0;
+    if (RFOLD && rflag) {
+        for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // validation: monotone and sums to M
+    {
+        u32 bad = 0;
+        for (u32 s = tid; s < ns; s += nt) bad |= (cum[s + 1] < cum[s]) ? 1u : 0u;
+        if (tid == 0 && cum[ns] != M) bad = 1;
+        if (bad) {
+            sh_hdr[4] = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+        }
+    }
+    __syncthreads();
+    if (sh_hdr[4]) return;
+    // ---- 2. slot -> symbol table
+    {
+        const u32 per = (M + nt - 1) / nt;
+        const u32 lo = tid * per;
+        u32 hi = lo + per;
+        hi = hi < M ? hi : M;
+        if (lo < M) {
+            // last s with cum[s] <= lo
+            u32 a = 0, z = ns;  // invariant cum[a] <= lo < cum[z]
+            while (z - a > 1) {
+                u32 mid = (a + z) >> 1;
+                if (cum[mid] <= lo) a = mid;
+                else z = mid;
+            }
+            u32 s = a;
+            for (u32 slot = lo; slot < hi; slot++) {
+                while (cum[s + 1] <= slot) s++;
+                s2s[slot] = (u16)s;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 3. decode
+    const u32 nseg = geo_nseg(nb, g.ckpt);
+    const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
+    const u64 Lb = (u64)16 << logM;
+    const u32 mask = M - 1;
+    u32* o = outp + (u64)b * g.block_ints;
+    const u32 rtail = nb & 3, nfull = nb - rtail;
+    for (u32 seg = quad; seg < nseg; seg += nq) {
+        u64 st;
+        int p;
+        if (seg == 0) {  // ans_fold.hpp:289-295: states 3,2,1,0 from the end
+            st = ld_u64_unaligned(stream + sbytes - 32 + 8 * (3 - ql)) + Lb;
+            p = (int)sbytes - 32;
+        } else {
+            const u64 idx = (u64)b * g.nckf + (seg - 1);
+            st = ckpt_state[idx * 4 + (3 - ql)];
+            u32 po = ckpt_off[idx];
+            p = (int)(po < sbytes ? po : sbytes);
+        }
+        const u32 start = seg * g.ckpt;
+        u32 end = (seg == nseg - 1) ? nfull : (start + g.ckpt);
+        end = end < nfull ? end : nfull;
+        for (u32 i = start; i < end; i += 4) {
+            u32 val = dec_step<RFOLD>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream);
+            o[i + ql] = val;
+        }
+        if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
+            for (u32 i = nfull; i < nb; i++) {
+                u32 val = dec_step<RFOLD>(st, p, ql == 3, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream);
+                if (ql == 3) o[i] = val;
+            }
+        }
+    }
+}

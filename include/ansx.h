@@ -1,0 +1,145 @@
+/*
+ * ansx — MI355X-native ANSfold / ANSrfold codec: C-ABI boundary.
+ *
+ * This is the drop-in boundary for ONE hot path of mpetri/ans-large-alphabet: the
+ * ANSfold<f> / ANSrfold<f> encode()/decode() pair.  Plain pointers and sizes only, so any host
+ * language can bind it (the reference is header-only C++17 and has no FFI; the C++ mirror with
+ * the reference's exact static signatures is ans_large_alphabet_amd/include/ansx_methods.hpp).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *
+ *   ansx_encode / ansx_encode_dev   ANSfold<f>::encode   include/methods.hpp:535-540
+ *                                   -> ans_fold_compress<f>           include/ans_fold.hpp:238-281
+ *                                   ANSrfold<f>::encode  include/methods.hpp:555-560
+ *                                   -> ans_reorder_fold_compress<f>   include/ans_reorder_fold.hpp:312-355
+ *   ansx_decode / ansx_decode_dev   ANSfold<f>::decode   include/methods.hpp:541-546
+ *                                   -> ans_fold_decompress<f>         include/ans_fold.hpp:283-311
+ *                                   ANSrfold<f>::decode  include/methods.hpp:561-566
+ *                                   -> ans_reorder_fold_decompress<f> include/ans_reorder_fold.hpp:357-385
+ *   ansx_bound                      the harness's "n*8 bytes" output sizing, src/table_efficiency.cpp:73-74
+ *                                   (the reference never checks dstCapacity, ans_fold.hpp:239-240)
+ *   ansx_codec_name                 ANSfold<f>::name / ANSrfold<f>::name  include/methods.hpp:530-533,550-553
+ *
+ * Output format.  A reference encode() call is 4 serial rANS chains, so device
+ * parallelism comes from independent blocks.  With opts.block_ints != ANSX_SINGLE_STREAM the
+ * output is a *container*: a 64-byte header, a block index, decoder restart points, then the
+ * concatenation of one UNMODIFIED reference stream per block — each block's bytes are
+ * identical to what ANSfold<f>::encode(block) / ANSrfold<f>::encode(block) writes (modulo the
+ * reference's own indeterminate padding bits, SURVEY F2, which are written as zero).
+ * With opts.block_ints == ANSX_SINGLE_STREAM the output is exactly one reference stream for the
+ * whole list (no header); ansx_decode with the same option accepts streams produced by the
+ * reference CPU encoder.  Container layout: see DESIGN.md section 3 and ansx_container_header.
+ *
+ * Errors: the reference has none on this path (malformed input is UB, capacity is unchecked);
+ * every function here returns an ansx_status instead.  n == 0 is an error (the reference never
+ * terminates on it); values must be < 2^30 (rfold: value + 2^(f+7) < 2^30), the
+ * reference's own decode limit (ans_fold.hpp:198-200).
+ *
+ * Threading: a context is bound to one device and must not be used from two host threads at
+ * once; distinct contexts are independent (the reference codec is stateless and re-entrant).
+ */
+#ifndef ANSX_H
+#define ANSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ansx_ctx ansx_ctx;
+
+typedef enum {
+    ANSX_FOLD = 0, /* ANSfold<f>  */
+    ANSX_RFOLD = 1 /* ANSrfold<f> */
+} ansx_kind;
+
+typedef enum {
+    ANSX_OK = 0,
+    ANSX_ERR_ARG = 1,       /* bad kind / fidelity / n == 0 / null pointer / bad options      */
+    ANSX_ERR_CAPACITY = 2,  /* output buffer too small (see ansx_bound)                        */
+    ANSX_ERR_FORMAT = 3,    /* container/stream failed validation                              */
+    ANSX_ERR_HIP = 4,       /* a HIP runtime call failed (ansx_last_hip_error has the code)    */
+    ANSX_ERR_NO_DEVICE = 5, /* no usable gfx950 device                                         */
+    ANSX_ERR_DOMAIN = 6,    /* an input value is outside the reference's decodable domain      */
+    ANSX_ERR_MODEL = 7      /* normalisation hit the reference's degenerate exit   */
+} ansx_status;
+
+#define ANSX_SINGLE_STREAM 0xFFFFFFFFu /* opts.block_ints: one plain reference stream          */
+#define ANSX_NO_CHECKPOINTS 0xFFFFFFFFu /* opts.ckpt_interval: no decoder restart points        */
+#define ANSX_DEFAULT_BLOCK_INTS 16384u
+#define ANSX_DEFAULT_CKPT_INTERVAL 1024u
+
+typedef struct {
+    uint32_t block_ints;    /* ints per independent reference stream; 0 = default             */
+    uint32_t ckpt_interval; /* ints between decoder restart points (multiple of 4); 0 = default */
+    uint32_t flags;         /* reserved, must be 0                                             */
+    uint32_t reserved;
+} ansx_opts;
+
+/* 64-byte container header (little endian), see DESIGN.md section 3. */
+typedef struct {
+    uint8_t magic[8];       /* "ANSXv1\0\0"                                                    */
+    uint32_t kind;
+    uint32_t fidelity;
+    uint64_t n;             /* total ints                                                       */
+    uint32_t block_ints;
+    uint32_t ckpt_interval; /* 0 = none                                                         */
+    uint32_t nblocks;
+    uint32_t max_log2_frame; /* max over blocks of log2(M)                                      */
+    uint32_t max_nsyms;      /* max over blocks of max_sym + 1                                  */
+    uint32_t ckpts_per_block; /* restart points stored per block (fixed stride)                 */
+    uint64_t payload_bytes;  /* sum of block stream sizes                                       */
+    uint64_t payload_offset; /* byte offset of the first block stream                           */
+} ansx_container_header;
+
+typedef struct {
+    char name[48];
+    double total_ms;
+    uint64_t launches;
+} ansx_kernel_time;
+
+/* Context: one per (process, device).  device < 0 -> current device. */
+int ansx_init(int device, ansx_ctx** ctx);
+void ansx_destroy(ansx_ctx* ctx);
+
+const char* ansx_strerror(int status);
+int ansx_last_hip_error(const ansx_ctx* ctx);
+/* "ANSfold-<f>" / "ANSrfold-<f>" (methods.hpp:530-533,550-553); returns chars written. */
+int ansx_codec_name(int kind, int fidelity, char* buf, size_t buflen);
+
+/* Worst-case output bytes for n ints with these options (>= any actual output). */
+size_t ansx_bound(int kind, int fidelity, size_t n, const ansx_opts* opts);
+
+/* Host-buffer entry points (H2D + device path + D2H). */
+int ansx_encode(ansx_ctx* ctx, int kind, int fidelity, const uint32_t* in, size_t n, uint8_t* out,
+    size_t out_capacity, size_t* out_bytes, const ansx_opts* opts);
+int ansx_decode(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* in, size_t in_bytes,
+    uint32_t* out, size_t n, const ansx_opts* opts);
+
+/* Device-pointer entry points: in/out are HBM resident; `stream` is a hipStream_t (NULL = the
+ * context's own stream).  They return after the result size / status has been read back. */
+int ansx_encode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint32_t* d_in, size_t n,
+    uint8_t* d_out, size_t out_capacity, size_t* out_bytes, const ansx_opts* opts, void* stream);
+int ansx_decode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* d_in, size_t in_bytes,
+    uint32_t* d_out, size_t n, const ansx_opts* opts, void* stream);
+
+/* Parse + validate a container header held in HOST memory. */
+int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out);
+
+/* Per-kernel device timing (hipEvent pairs around every launch) for bench.py's roofline leg. */
+int ansx_profile_enable(ansx_ctx* ctx, int on);
+int ansx_profile_reset(ansx_ctx* ctx);
+int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int* count);
+
+/* Bytes of device workspace currently held by the context. */
+size_t ansx_workspace_bytes(const ansx_ctx* ctx);
+
+/* Host evaluation of the portable log2 used by the device normaliser (unit tests only). */
+double ansx_host_log2(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANSX_H */

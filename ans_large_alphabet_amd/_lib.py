@@ -54,6 +54,25 @@ def build_library(force=False):
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's); if libansx.so pulled in
+    /opt/rocm's copy first, a later `import torch` would load a second runtime and find no GPU.
+    So when torch is installed, load ITS runtime first (without importing torch); libansx.so's
+    NEEDED libamdhip64.so.7 then binds to that already-loaded object."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # a C++-only deployment simply uses /opt/rocm's runtime
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -62,6 +81,7 @@ def lib():
         raise ImportError(
             "libansx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ans_large_alphabet_amd/csrc` (needs hipcc); there is no CPU fallback")
+    _preload_shared_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
     L.ansx_init.restype = C.c_int

@@ -133,9 +133,20 @@ ANSX_HD double ansx_log2_portable(double x)
 // ---------------------------------------------------------------------------------------------
 #define ANSX_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 
+// quad_perm through an explicit DPP mov.  Inline asm on purpose: with the builtin
+// (__builtin_amdgcn_mov_dpp) hipcc -O3 (ROCm 7.2) folds the [3,3,3,3] broadcast into the
+// cursor update as `v_subrev_u32_dpp p, incl, p`, and that folded form returned the lane's OWN
+// value instead of lane 3's on MI355X (measured: decode cursors diverged inside a quad; -O1, a
+// ds_bpermute shuffle, or this asm form are all correct).  The asm statement cannot be combined
+// with its consumer; `s_nop 1` covers the 2 wait states a DPP read needs after a VALU write of
+// the same VGPR (hipcc pads nothing inside asm).
 template <int CTRL> ANSX_D u32 quad_perm(u32 v)
 {
-    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+    u32 r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=v"(r)
+                 : "v"(v), "n"(CTRL & 3), "n"((CTRL >> 2) & 3), "n"((CTRL >> 4) & 3), "n"((CTRL >> 6) & 3));
+    return r;
 }
 
 // inclusive prefix sum over the 4 lanes of a quad; *total receives the quad sum

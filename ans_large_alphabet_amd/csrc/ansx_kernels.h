@@ -770,6 +770,9 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
         const u32 T = fold_T(f);
         if (rflag) val = (sym < T) ? mf[sym] : (val - T);  // ans_reorder_fold.hpp:207-219,300-301
     }
+#ifdef ANSX_DEBUG
+    printf("dec lane %u sym %u fr %u k %u rn %d c %u incl %u total %u p %d myp %d v %016llx e %u val %u\n", ql, sym, fr, k, (int)rn, c, incl, total, p, myp, (unsigned long long)v, e, val);
+#endif
     p -= (int)total;
     return val;
 }

@@ -41,8 +41,8 @@ struct ansx_ctx {
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
-    DevBuf hist, sortF, sortSym, attS, prevS, attMeta, blk, table, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, plain, rf_tmp;
+    DevBuf hist, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
 };
 
@@ -209,6 +209,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 8))) return rc;
     if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
     if ((rc = ensure(c, c->table, (size_t)NB * NSP * sizeof(ansx_enc_entry)))) return rc;
+    if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
     u32* gflags = (u32*)c->misc.p;
@@ -255,16 +256,33 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
             (u16*)c->attS.p, (u32*)c->attMeta.p);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
-            (ansx_enc_entry*)c->table.p, gflags, batch == nbatch - 1 ? 1u : 0u);
+            (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);
     }
     // K3
     LAUNCH(c, "k_write_prelude", k_write_prelude, NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
         (const ansx_enc_entry*)c->table.p, hist, blk, (u8*)c->scratch.p, (u64)scr_stride, mostfreq);
-    // K5
+    // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit; their size depends on
+    // the largest alphabet / frame actually produced, so read those two words back first.
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    {
+        int st0 = flags_to_status(c->h_pin[ANSX_G_ERR]);
+        if (st0) return st0;
+    }
+    const u32 max_logM = c->h_pin[ANSX_G_MAXLOGM], max_ns = c->h_pin[ANSX_G_MAXNSYMS];
     u64* ck_state = P.plain ? nullptr : (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = P.plain ? nullptr : (u32*)(d_out + P.lay.ckoff_off);
-    LAUNCH(c, "k_encode", k_encode, ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
-        (const ansx_enc_entry*)c->table.p, blk, (u8*)c->scratch.p, (u64)scr_stride, ck_state, ck_off);
+    const u32 lds_stride = max_ns | 1u;  // odd stride spreads the 16 tables over the banks
+    const size_t enc_lds = (size_t)16 * lds_stride * 4;
+    if (max_logM <= 16 && enc_lds <= 40 * 1024) {
+        LAUNCH(c, "k_encode", (k_encode<true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off);
+    } else {
+        LAUNCH(c, "k_encode_gtab", (k_encode<false>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
+            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off);
+    }
     // K6
     u64* boff = P.plain ? boff_ws : (u64*)(d_out + P.lay.index_off);
     LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off,
@@ -287,32 +305,62 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32* gflags, hipStream_t s)
+    u32 max_block_bytes, u32* gflags, hipStream_t s)
 {
     const u32 T = fold_T(g.f);
+    int rc;
+    if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
+    if ((rc = ensure(c, c->dec_info, (size_t)g.nblocks * 16))) return rc;
+    // K7: one lane per block, bpw blocks per wave, preludes staged in LDS
+    const u32 pw = (u32)rup(max_ns + 12, 4);  // words per staged prelude (<= 32 bits per item)
+    u32 bpw = 16;
+    while (bpw > 1 && (size_t)bpw * pw * 4 > 96 * 1024) bpw >>= 1;
+    const size_t plds = (size_t)bpw * pw * 4;
+    if (plds > 150 * 1024) return ANSX_ERR_FORMAT;
+    if (plds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude<RF>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+    LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + bpw - 1) / bpw, 64, plds, s, cont, g, NSP,
+        boff, payload_off, max_ns, maxM, bpw, pw, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    // K8
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
     u32 threads = (u32)rup((size_t)nseg * 4, 64);
     if (threads > 256) threads = 256;
-    size_t cb = rup(((size_t)max_ns + 2) * 4, 16);
-    size_t lds = cb + rup((size_t)maxM * 2, 16) + (RF ? (size_t)T * 4 : 0);
+    const size_t cb = rup(((size_t)max_ns + 2) * 4, 16);
+    const size_t s2sb = rup((size_t)maxM * 2, 16);
+    const size_t mfb = RF ? (size_t)T * 4 : 0;
+    const size_t tables = cb + s2sb + mfb;
     const size_t LDS_LIMIT = 150 * 1024;
-    if (lds <= LDS_LIMIT) {
+    // stage the block stream in LDS when (tables + stream) still leaves >= 3 workgroups per CU
+    size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
+    if (tables <= LDS_LIMIT) {
+        size_t lds = tables;
+        u32 stream_cap = 0;
+        if (tables + want_stream <= 52 * 1024) {
+            lds += want_stream;
+            stream_cap = (u32)want_stream;
+        }
         if (lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_decode<true, RF>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LAUNCH(c, "k_decode", (k_decode<true, RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
-            ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u16*)nullptr, (u32*)nullptr, gflags);
+            ck_state, ck_off, payload_off, d_out, maxM, max_ns, stream_cap, (u16*)nullptr,
+            (u32*)c->dec_cum.p, (const uint4*)c->dec_info.p, gflags);
     } else {
-        int rc;
         if ((rc = ensure(c, c->dec_s2s, (size_t)g.nblocks * maxM * 2))) return rc;
-        if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
-        size_t l2 = RF ? (size_t)T * 4 : 16;
-        if (l2 > 48 * 1024)
+        size_t lds = mfb;
+        u32 stream_cap = 0;
+        if (mfb + want_stream <= 52 * 1024) {
+            lds += want_stream;
+            stream_cap = (u32)want_stream;
+        }
+        if (lds < 16) lds = 16;
+        if (lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_decode<false, RF>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-        LAUNCH(c, "k_decode_gtab", (k_decode<false, RF>), g.nblocks, threads, l2, s, cont, g, NSP, boff,
-            ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u16*)c->dec_s2s.p, (u32*)c->dec_cum.p,
-            gflags);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_decode_gtab", (k_decode<false, RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
+            ck_state, ck_off, payload_off, d_out, maxM, max_ns, stream_cap, (u16*)c->dec_s2s.p,
+            (u32*)c->dec_cum.p, (const uint4*)c->dec_info.p, gflags);
     }
     return ANSX_OK;
 }
@@ -327,6 +375,7 @@ __global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 p
     if (i == 0 && a != 0) bad = true;
     if (i == g.nblocks - 1 && b != payload_bytes) bad = true;
     if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+    else atomicMax(&gflags[ANSX_G_PAD], (u32)(b - a));  // largest block stream (sizes the LDS staging)
 }
 
 int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
@@ -351,7 +400,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
     const u32 f = P.g.f;
     const u32 T = fold_T(f);
-    u32 maxM, max_ns;
+    u32 maxM, max_ns, max_block_bytes;
     const u8* cont;
     const u64* boff;
     const u64* ck_state = nullptr;
@@ -399,6 +448,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         cont = (const u8*)c->plain.p;
         boff = boff_ws;
         payload_off = 16;
+        max_block_bytes = (u32)in_bytes;
     } else {
         u8* hp = (u8*)c->h_pin + 64;
         if (in_bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
@@ -433,13 +483,14 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
+        max_block_bytes = c->h_pin[ANSX_G_PAD];
     }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, gflags, s);
+            max_ns, max_block_bytes, gflags, s);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, gflags, s);
+            max_ns, max_block_bytes, gflags, s);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -486,8 +537,8 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
-        &c->table, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->plain, &c->rf_tmp };
+        &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {
@@ -661,8 +712,8 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
 {
     if (!c) return 0;
     const DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
-        &c->table, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->plain, &c->rf_tmp };
+        &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
     size_t t = 0;
     for (const DevBuf* b : bufs) t += b->cap;
     return t;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
 __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u16* __restrict__ attS, const u32* __restrict__ attMeta,
     u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
-    u32* __restrict__ gflags, u32 last_batch)
+    u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch)
 {
     __shared__ double terms[1024];
     __shared__ int sh_flag;
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     u32 run = 0;
     for (u32 l = 0; l < lane; l++) run += sh_part[l];
     ansx_enc_entry* tab = table + (u64)b * NSP;
+    u32* t32 = tab32 + (u64)b * NSP;
     for (u32 s = lo; s < hi; s++) {
         u32 fr = h[s] ? (u32)S[s] : 0u;
         ansx_enc_entry e;
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         e.freq = fr;
         e.rcp = fr ? 1.0 / (double)fr : 0.0;
         tab[s] = e;
+        t32[s] = (run << 16) | fr;  // valid while M <= 65536 (base < 2^16, freq < 65535)
         run += fr;
     }
     if (lane == 0) {
@@ -557,50 +559,111 @@ struct enc_lane {
     u32 p;  // byte cursor relative to the block's stream start (uniform within the quad)
 };
 
-__device__ __forceinline__ void enc_step(enc_lane& L, u32 x, bool active, u32 ql, u32 f, u32 logM,
-    const ansx_enc_entry* __restrict__ tab, u8* __restrict__ out)
+// one symbol of one state.  x: value; (freq, base, rcp): its table entry, fetched ahead of the
+// dependency chain.
+__device__ __forceinline__ void enc_update(enc_lane& L, u32 x, u32 freq, u32 base, double rcp,
+    bool active, u32 ql, u32 f, u32 logM, u8* __restrict__ out)
 {
     const u32 k = fold_nbytes(f, x);
-    const u32 sym = fold_sym(f, x, k);
     const u32 eb = x & ((1u << (8 * k)) - 1u);
-    const ansx_enc_entry e = tab[sym];
     u64 st = L.st;
     // renormalise: state >= K*RADIX*freq  <=>  (state >> 36) >= freq   (ans_fold.hpp:105-110)
-    const bool rn = active && ((u32)(st >> 36) >= e.freq);
+    const bool rn = active && ((u32)(st >> 36) >= freq);
     const u32 w = (u32)st;
     if (rn) st >>= 32;
-    // exact q = st / freq, r = st % freq; st < 2^36 * freq <= 2^52 (ans_fold.hpp:111)
-    double qd = (double)st * e.rcp;
+    // exact q = st / freq, r = st % freq; st < 2^36 * freq <= 2^52 (ans_fold.hpp:111).
+    // rcp is 1/freq to < 2^-40 relative, so trunc(st * rcp) is within +-1 of the quotient.
+    double qd = (double)st * rcp;
     u64 q = (u64)qd;
-    i64 r = (i64)st - (i64)(q * (u64)e.freq);
+    i64 r = (i64)st - (i64)(q * (u64)freq);
     if (r < 0) {
         q -= 1;
-        r += e.freq;
-    } else if (r >= (i64)e.freq) {
+        r += freq;
+    } else if (r >= (i64)freq) {
         q += 1;
-        r -= e.freq;
+        r -= freq;
     }
-    st = (q << logM) + (u64)r + (u64)e.base;
+    st = (q << logM) + (u64)r + (u64)base;
     if (active) L.st = st;
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
     u32 total;
     const u32 incl = quad_incl_scan(c, ql, &total);
     u8* a = out + L.p + (incl - c);
+#ifndef ANSX_ABL_NOSTORE
     if (active) {
         if (k == 1) a[0] = (u8)eb;
         if (k >= 2) st_u16_unaligned(a, (u16)eb);
         if (k == 3) a[2] = (u8)(eb >> 16);
         if (rn) st_u32_unaligned(a + k, w);
     }
+#else
+    asm volatile("" ::"v"(a), "v"(eb), "v"(w));
+#endif
     L.p += total;
 }
 
+// table access: LDS-resident compact entries (base << 16 | freq) or the 16-byte global entries
+template <bool LDS_TABLE> struct enc_tab;
+template <> struct enc_tab<false> {
+    const ansx_enc_entry* t;
+    struct ent {
+        u32 freq, base;
+        double rcp;
+    };
+    __device__ __forceinline__ ent get(u32 sym) const
+    {
+        ansx_enc_entry e = t[sym];
+        ent r;
+        r.freq = e.freq;
+        r.base = e.base;
+        r.rcp = e.rcp;
+        return r;
+    }
+};
+template <> struct enc_tab<true> {
+    const u32* t;  // LDS
+    struct ent {
+        u32 freq, base;
+        double rcp;
+    };
+    __device__ __forceinline__ ent get(u32 sym) const
+    {
+        const u32 e = t[sym];
+        ent r;
+        r.freq = e & 0xFFFFu;
+        r.base = e >> 16;
+        // 1/freq: hardware seed + one Newton step (relative error ~2^-50, far below the 2^-37
+        // the +-1 correction in enc_update needs)
+        const double fd = (double)r.freq;
+        const double r0 = __builtin_amdgcn_rcp(fd);
+        r.rcp = __builtin_fma(__builtin_fma(-fd, r0, 1.0), r0, r0);
+        return r;
+    }
+};
+
+#define ANSX_ENC_U 8  // symbols per lane kept in flight by the software pipeline
+
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
-    const ansx_enc_entry* __restrict__ table, ansx_blk* __restrict__ blk, u8* __restrict__ scratch,
-    u64 scr_stride, u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
+    const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
+    u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
 {
+    extern __shared__ u32 lds_tab[];
     const u32 gt = blockIdx.x * 64 + threadIdx.x;
     const u32 b = gt >> 2, ql = gt & 3;
+    if (LDS_TABLE) {
+        // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries)
+        const u32 b0 = blockIdx.x * 16;
+        for (u32 j = 0; j < 16; j++) {
+            const u32 bj = b0 + j;
+            if (bj >= g.nblocks) break;
+            const u32 nsj = blk[bj].max_sym + 1;
+            const u32* src32 = tab32 + (u64)bj * NSP;
+            for (u32 s = threadIdx.x; s < nsj; s += 64) lds_tab[j * lds_stride + s] = src32[s];
+        }
+        __syncthreads();
+    }
     if (b >= g.nblocks) return;
     ansx_blk* B = &blk[b];
     if (B->status) {
@@ -609,28 +672,29 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     }
     const u32 nb = geo_block_n(g, b);
     const u32* src = in + (u64)b * g.block_ints;
-    const ansx_enc_entry* tab = table + (u64)b * NSP;
+    enc_tab<LDS_TABLE> tab;
+    if constexpr (LDS_TABLE) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
+    else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
     const u32 f = g.f, logM = B->logM;
     const u64 Lb = (u64)16 << logM;
     enc_lane L;
     L.st = Lb;
     L.p = B->prelude_bytes;
+    auto lookup = [&](u32 x) { return tab.get(fold_sym(f, x, fold_nbytes(f, x))); };
     const u32 r = nb & 3;
     // tail symbols all go to state 0 (ans_fold.hpp:257-261)
     for (u32 t = 0; t < r; t++) {
         u32 x = src[nb - 1 - t];
-        enc_step(L, x, ql == 0, ql, f, logM, tab, out);
+        auto e = lookup(x);
+        enc_update(L, x, e.freq, e.base, e.rcp, ql == 0, ql, f, logM, out);
     }
     // groups of four, backwards (ans_fold.hpp:262-272): in[4g+3-q] -> state q
     const u32 G = nb >> 2;
     const u32 cg = g.ckpt >> 2;  // groups per restart interval (0 = none)
     u32 ck_seg = (cg && G) ? (G - 1) / cg : 0;  // next restart point to record: segment index
     u32 ck_g = ck_seg * cg;                     // ... and its group index
-    for (u32 gi = G; gi > 0; gi--) {
-        const u32 gidx = gi - 1;
-        u32 x = src[4 * gidx + 3 - ql];
-        enc_step(L, x, true, ql, f, logM, tab, out);
+    auto record = [&](u32 gidx) {
         // every symbol with index >= 4*gidx is now encoded: decoder restart point of segment
         // ck_seg (the decoder of that segment starts with exactly these states and cursor)
         if (ck_seg && gidx == ck_g) {
@@ -639,6 +703,59 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
             if (ql == 0) ckpt_off[idx] = L.p;
             ck_seg--;
             ck_g -= cg;
+        }
+    };
+    u32 gi = G;  // groups [0, gi) remain
+    // leading remainder so that the pipelined part covers a multiple of U groups
+    for (u32 t = G % ANSX_ENC_U; t > 0; t--) {
+        const u32 gidx = --gi;
+        u32 x = src[4 * gidx + 3 - ql];
+        auto e = lookup(x);
+        enc_update(L, x, e.freq, e.base, e.rcp, true, ql, f, logM, out);
+        record(gidx);
+    }
+    // software pipeline over batches of U groups: while batch t is encoded, the table entries
+    // of batch t+1 and the inputs of batch t+2 are in flight, so the per-symbol dependency
+    // chain (renorm test -> divide -> state) never waits on memory.
+    if (gi) {
+        const u32* base = src + 3 - ql;
+        u32 x1[ANSX_ENC_U], x2[ANSX_ENC_U];
+        typename enc_tab<LDS_TABLE>::ent e1[ANSX_ENC_U];
+#pragma unroll
+        for (int j = 0; j < ANSX_ENC_U; j++) x1[j] = base[4 * (gi - 1 - j)];
+#pragma unroll
+        for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = lookup(x1[j]);
+        if (gi >= 2 * ANSX_ENC_U) {
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (gi - ANSX_ENC_U - 1 - j)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = 0;
+        }
+        while (gi) {
+            u32 x0[ANSX_ENC_U];
+            typename enc_tab<LDS_TABLE>::ent e0[ANSX_ENC_U];
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_U; j++) {
+                x0[j] = x1[j];
+                e0[j] = e1[j];
+                x1[j] = x2[j];
+            }
+            const u32 top = gi;  // this batch encodes groups top-1 ... top-U
+            if (top >= 2 * ANSX_ENC_U) {
+#pragma unroll
+                for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = lookup(x1[j]);
+            }
+            if (top >= 3 * ANSX_ENC_U) {
+#pragma unroll
+                for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (top - 2 * ANSX_ENC_U - 1 - j)];
+            }
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_U; j++) {
+                enc_update(L, x0[j], e0[j].freq, e0[j].base, e0[j].rcp, true, ql, f, logM, out);
+                record(top - 1 - j);
+            }
+            gi = top - ANSX_ENC_U;
         }
     }
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
@@ -737,16 +854,158 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
 //      bytes) are located by a quad prefix sum, one unaligned 8-byte load per lane and step.
 // Tables live in LDS (LDS_TAB) or, for very large frames, in a global workspace.
 // ------------------------------------------------------------------------------------------
-struct dec_tables {
-    u32* cum;   // [ns+1]
-    u16* s2s;   // [M]
-    u32* mf;    // rfold: most-frequent table [T] (LDS copy) or nullptr
-};
-
+// ---- K7: prelude parse.  Bit parsing of the interpolative code is serial per block, so blocks
+// are spread over LANES: each wave stages the preludes of `bpw` blocks in LDS (coalesced
+// copies) and lanes 0..bpw-1 each walk one of them (interp.hpp:47-63,81-97; vbyte.hpp:82-95;
+// ans_util.hpp:25-42).  Output per block: inc[] in the global table row (cum[s+1] = inc[s],
+// un-prefix-summed later) and {nsyms, log2 M, rfold flag, error}.
 template <bool RFOLD>
+__global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, u32 bpw, u32 pw,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+{
+    extern __shared__ u32 lds_pre[];  // bpw x pw words
+    __shared__ u32 sh_ipos[16], sh_ns[16], sh_sb[16];
+    __shared__ u32 stk[16][4 * 20];
+    const u32 lane = threadIdx.x;
+    const u32 T = fold_T(g.f);
+    const u32 b0 = blockIdx.x * bpw;
+    u32 err = 0, ns = 0, logM = 0, flag = 0, ipos = 0, sbytes = 0;
+    const u32 b = b0 + lane;
+    const bool mine = lane < bpw && b < g.nblocks;
+    if (mine) {
+        const u64 boff = block_off[b];
+        const u8* stream = cont + payload_off + boff;
+        sbytes = (u32)(block_off[b + 1] - boff);
+        u32 pos = 0;
+        if (RFOLD) {  // ans_reorder_fold.hpp:238-254
+            flag = ld_u32_unaligned(stream);
+            pos = 4 + (flag == 1 ? 4 * T : 0);
+            if (flag > 1) err = 1;
+        }
+        u32 ms = 0, shv = 0;  // vbyte (vbyte.hpp:82-95)
+        if (!err && sbytes >= pos + 38) {
+            for (int i = 0; i < 5; i++) {
+                u8 cbyte = stream[pos++];
+                ms += (u32)(cbyte & 127) << shv;
+                if (!(cbyte & 128)) break;
+                shv += 7;
+            }
+            logM = stream[pos++];
+        } else {
+            err = 1;
+        }
+        ns = ms + 1;
+        if (ns > max_ns || ns > NSP || logM > 31 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
+        ipos = pos;
+    }
+    if (lane < 16) {
+        sh_ipos[lane] = ipos;
+        sh_ns[lane] = (mine && !err) ? ns : 0;
+        sh_sb[lane] = sbytes;
+    }
+    __syncthreads();
+    // stage the interpolative words of every block of this wave
+    for (u32 j = 0; j < bpw; j++) {
+        const u32 nsj = sh_ns[j];
+        if (nsj == 0) continue;
+        const u64 boff = block_off[b0 + j];
+        const u8* sj = cont + payload_off + boff + sh_ipos[j];
+        u32 want = 4 * nsj + 16, avail = sh_sb[j] - sh_ipos[j];
+        u32 nbytes = want < avail ? want : avail;
+        u32 nw = (nbytes + 3) >> 2;
+        if (nw > pw - 2) nw = pw - 2;
+        u32* dst = lds_pre + j * pw;
+        for (u32 w = lane; w < nw; w += 64) dst[w] = ld_u32_unaligned(sj + 4 * (u64)w);
+        if (lane == 0) {
+            dst[nw] = 0;
+            dst[nw + 1] = 0;
+        }
+    }
+    __syncthreads();
+    if (mine && !err) {
+        const u32* pre = lds_pre + lane * pw;
+        u32* cum = g_cum + (u64)b * (NSP + 8);
+        u32* st = stk[lane];
+        u32 bitpos = 0;
+        const u32 maxbits = (sbytes - ipos) * 8;
+        auto getbits = [&](u32 nbits) -> u32 {
+            if (nbits == 0) return 0u;
+            const u32 wi = bitpos >> 5, sh = bitpos & 31;
+            const u64 two = (u64)pre[wi] | ((u64)pre[wi + 1] << 32);
+            bitpos += nbits;
+            return (u32)((two >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
+        };
+        const u64 u = ((u64)1 << logM) + ns + 1;
+        u32 sp = 1;
+        st[0] = 0;
+        st[1] = ns;
+        st[2] = 1;
+        st[3] = (u32)(u + 1);
+        while (sp > 0 && !err) {
+            sp--;
+            u32 a = st[4 * sp], n = st[4 * sp + 1];
+            u64 low = st[4 * sp + 2], high = st[4 * sp + 3];
+            while (n > 0) {
+                const u32 h = (n + 1) >> 1;
+                const u64 n1 = h - 1, n2 = n - h;
+                const u64 U = high - n2 - low - n1 + 1;
+                if ((i64)U < 1 || bitpos > maxbits) {
+                    err = 1;
+                    break;
+                }
+                u64 val = 1;  // read_center_mid (interp.hpp:47-63)
+                const u32 bb = (U == 1) ? 0u : (64 - __clzll((unsigned long long)(U - 1)));
+                const u64 d = 2ull * U - (1ull << bb);
+                if (U != 1) {
+                    const u64 m = (1ull << bb) - U;
+                    val = (u64)getbits(bb - 1) + 1;
+                    if (val > m) val = (2ull * val + getbits(1)) - m - 1ull;
+                }
+                val = val + (d >> 1);
+                if (val > U) val -= U;
+                const u64 v = low + n1 - 1ull + val;
+                cum[a + h] = (u32)(v - 1);  // inc[a+h-1]
+                if (n2) {
+                    st[4 * sp] = a + h;
+                    st[4 * sp + 1] = (u32)n2;
+                    st[4 * sp + 2] = (u32)(v + 1);
+                    st[4 * sp + 3] = (u32)high;
+                    sp++;
+                }
+                n = (u32)n1;
+                high = v - 1;
+            }
+        }
+    }
+    if (mine) {
+        binfo[b] = make_uint4(ns, logM, flag, err);
+        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    }
+}
+
+// 8 stream bytes ending at byte offset `end` (exclusive): from the LDS-staged copy (aligned
+// words + v_alignbyte) or straight from global memory (one unaligned 8-byte load)
+template <bool STREAM_LDS>
+__device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end)
+{
+    if (STREAM_LDS) {
+        // lds_stream word 0 holds stream bytes [-8,-4): byte a of the stream is at lds byte a+8
+        const u32 a = (u32)end;  // = (end - 8) + 8
+        const u32 w = a >> 2, sh = a & 3;
+        const u32 w0 = lds_stream[w], w1 = lds_stream[w + 1], w2 = lds_stream[w + 2];
+        const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        return ((u64)hi << 32) | lo;
+    } else {
+        return ld_u64_unaligned(stream + end - 8);
+    }
+}
+
+template <bool RFOLD, bool STREAM_LDS>
 __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u32 f, u32 logM,
     u32 mask, u64 Lb, const u32* cum, const u16* s2s, const u32* mf, u32 rflag,
-    const u8* __restrict__ stream)
+    const u8* __restrict__ stream, const u32* lds_stream)
 {
     const u32 slot = (u32)st & mask;
     const u32 sym = s2s[slot];
@@ -760,7 +1019,7 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
     const u32 incl = quad_incl_scan(c, ql, &total);
     int myp = p - (int)(incl - c);
     myp = myp < 0 ? 0 : myp;
-    const u64 v = ld_u64_unaligned(stream + myp - 8);
+    const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp);
     if (rn) ns_ = (ns_ << 32) | (v >> 32);  // ans_fold.hpp:221-225
     if (active) st = ns_;
     // exception bytes sit just below the renorm word (ans_fold.hpp:135-147)
@@ -770,181 +1029,21 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
         const u32 T = fold_T(f);
         if (rflag) val = (sym < T) ? mf[sym] : (val - T);  // ans_reorder_fold.hpp:207-219,300-301
     }
-#ifdef ANSX_DEBUG
-    printf("dec lane %u sym %u fr %u k %u rn %d c %u incl %u total %u p %d myp %d v %016llx e %u val %u\n", ql, sym, fr, k, (int)rn, c, incl, total, p, myp, (unsigned long long)v, e, val);
-#endif
     p -= (int)total;
     return val;
 }
 
-template <bool LDS_TAB, bool RFOLD>
-__global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
-    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
-    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
-    u32 max_ns, u16* __restrict__ g_s2s, u32* __restrict__ g_cum, u32* __restrict__ gflags)
+// decode every segment of one block (one quad of lanes per segment)
+template <bool RFOLD, bool STREAM_LDS>
+__device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u32 sbytes, u32 tid,
+    u32 nt, u32 f, u32 logM, const u32* cum, const u16* s2s, const u32* mfl, u32 rflag,
+    const u8* __restrict__ stream, const u32* lds_stream, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u32* __restrict__ o)
 {
-    extern __shared__ u8 smem[];
-    __shared__ u32 sh_hdr[8];  // ns, logM, interp byte offset, flag, error
-    __shared__ u32 stk[4 * 20];
-    const u32 tid = threadIdx.x, nt = blockDim.x;
-    const u32 b = blockIdx.x;
-    const u32 nb = geo_block_n(g, b);
-    const u64 boff = block_off[b];
-    const u8* stream = cont + payload_off + boff;
-    const u32 sbytes = (u32)(block_off[b + 1] - boff);
-    const u32 f = g.f;
-    const u32 T = fold_T(f);
-    u32* cum;
-    u16* s2s;
-    u32* mfl = nullptr;
-    if (LDS_TAB) {
-        cum = (u32*)smem;
-        u32 cb = ((max_ns + 2) * 4 + 15) & ~15u;
-        s2s = (u16*)(smem + cb);
-        if (RFOLD) mfl = (u32*)(smem + cb + (((u64)maxM * 2 + 15) & ~15ull));
-    } else {
-        cum = g_cum + (u64)b * (NSP + 8);
-        s2s = g_s2s + (u64)b * maxM;
-        if (RFOLD) mfl = (u32*)smem;
-    }
-    // ---- 1. prelude parse by lane 0
-    if (tid == 0) {
-        u32 err = 0;
-        u32 pos = 0, flag = 0;
-        if (RFOLD) {  // ans_reorder_fold.hpp:238-254
-            flag = ld_u32_unaligned(stream);
-            pos = 4 + (flag == 1 ? 4 * T : 0);
-            if (flag > 1) err = 1;
-        }
-        // vbyte (vbyte.hpp:82-95)
-        u32 ms = 0, shv = 0;
-        for (int i = 0; i < 5; i++) {
-            u8 cbyte = stream[pos++];
-            ms += (u32)(cbyte & 127) << shv;
-            if (!(cbyte & 128)) break;
-            shv += 7;
-        }
-        const u32 logM = stream[pos++];
-        const u32 ns = ms + 1;
-        if (ns > max_ns || ns > NSP || logM > 31 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
-        sh_hdr[0] = ns;
-        sh_hdr[1] = logM;
-        sh_hdr[3] = flag;
-        if (!err) {
-            // interpolative decode, iterative pre-order walk (interp.hpp:81-97)
-            const u8* bp = stream + pos;
-            u64 bitpos = 0;
-            const u64 maxbits = ((u64)sbytes - pos) * 8;
-            auto getbits = [&](u32 nbits) -> u32 {
-                if (nbits == 0) return 0u;
-                u64 byte = bitpos >> 3;
-                u32 sh = (u32)(bitpos & 7);
-                u64 wv = ld_u64_unaligned(bp + byte);
-                bitpos += nbits;
-                return (u32)((wv >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
-            };
-            const u64 u = ((u64)1 << logM) + ns + 1;
-            u32 sp = 0;
-            stk[0] = 0;
-            stk[1] = ns;
-            // low/high are < 2^33: store as two words each? they fit u32 when M <= 2^31 - ns
-            stk[2] = 1;
-            stk[3] = (u32)(u + 1);
-            sp = 1;
-            while (sp > 0 && !err) {
-                sp--;
-                u32 a = stk[4 * sp], n = stk[4 * sp + 1];
-                u64 low = stk[4 * sp + 2], high = stk[4 * sp + 3];
-                while (n > 0) {
-                    const u32 h = (n + 1) >> 1;
-                    const u64 n1 = h - 1, n2 = n - h;
-                    const u64 U = high - n2 - low - n1 + 1;
-                    if ((i64)U < 1 || bitpos > maxbits) {
-                        err = 1;
-                        break;
-                    }
-                    // read_center_mid (interp.hpp:47-63)
-                    u64 val = 1;
-                    const u32 bb = (U == 1) ? 0u : (64 - __clzll((unsigned long long)(U - 1)));
-                    const u64 d = 2ull * U - (1ull << bb);
-                    if (U != 1) {
-                        const u64 m = (1ull << bb) - U;
-                        val = (u64)getbits(bb - 1) + 1;
-                        if (val > m) val = (2ull * val + getbits(1)) - m - 1ull;
-                    }
-                    val = val + (d >> 1);
-                    if (val > U) val -= U;
-                    const u64 v = low + n1 - 1ull + val;
-                    cum[a + h] = (u32)(v - 1);  // inc[a+h-1], stored one slot up (see below)
-                    if (n2) {
-                        stk[4 * sp] = a + h;
-                        stk[4 * sp + 1] = (u32)n2;
-                        stk[4 * sp + 2] = (u32)(v + 1);
-                        stk[4 * sp + 3] = (u32)high;
-                        sp++;
-                    }
-                    n = (u32)n1;
-                    high = v - 1;
-                }
-            }
-        }
-        sh_hdr[4] = err;
-        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (sh_hdr[4]) return;
-    const u32 ns = sh_hdr[0], logM = sh_hdr[1], rflag = sh_hdr[3];
-    const u32 M = 1u << logM;
-    // inc[s] = sum_{t<=s} nfreq[t] + s  (ans_util.hpp:33-41)  ->  cum[s+1] = inc[s] - s
-    for (u32 s = tid; s < ns; s += nt) cum[s + 1] = cum[s + 1] - s;
-    if (tid == 0) cum[0] = 0;
-    if (RFOLD && rflag) {
-        for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
-    }
-    __threadfence_block();
-    __syncthreads();
-    // validation: monotone and sums to M
-    {
-        u32 bad = 0;
-        for (u32 s = tid; s < ns; s += nt) bad |= (cum[s + 1] < cum[s]) ? 1u : 0u;
-        if (tid == 0 && cum[ns] != M) bad = 1;
-        if (bad) {
-            sh_hdr[4] = 1;
-            atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
-        }
-    }
-    __syncthreads();
-    if (sh_hdr[4]) return;
-    // ---- 2. slot -> symbol table
-    {
-        const u32 per = (M + nt - 1) / nt;
-        const u32 lo = tid * per;
-        u32 hi = lo + per;
-        hi = hi < M ? hi : M;
-        if (lo < M) {
-            // last s with cum[s] <= lo
-            u32 a = 0, z = ns;  // invariant cum[a] <= lo < cum[z]
-            while (z - a > 1) {
-                u32 mid = (a + z) >> 1;
-                if (cum[mid] <= lo) a = mid;
-                else z = mid;
-            }
-            u32 s = a;
-            for (u32 slot = lo; slot < hi; slot++) {
-                while (cum[s + 1] <= slot) s++;
-                s2s[slot] = (u16)s;
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- 3. decode
     const u32 nseg = geo_nseg(nb, g.ckpt);
     const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
     const u64 Lb = (u64)16 << logM;
-    const u32 mask = M - 1;
-    u32* o = outp + (u64)b * g.block_ints;
+    const u32 mask = (1u << logM) - 1;
     const u32 rtail = nb & 3, nfull = nb - rtail;
     for (u32 seg = quad; seg < nseg; seg += nq) {
         u64 st;
@@ -961,15 +1060,142 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         const u32 start = seg * g.ckpt;
         u32 end = (seg == nseg - 1) ? nfull : (start + g.ckpt);
         end = end < nfull ? end : nfull;
-        for (u32 i = start; i < end; i += 4) {
-            u32 val = dec_step<RFOLD>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream);
-            o[i + ql] = val;
+        if (STREAM_LDS) {
+            for (u32 i = start; i < end; i += 4) {
+                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                o[i + ql] = val;
+            }
+        } else {
+            // The cursor walks down the stream ~4.5 bytes per step; pull the next 512 bytes
+            // (one 128-byte line per lane) towards the CU whenever it gets within 256 bytes of
+            // the prefetched frontier, so that the dependent 8-byte loads hit in cache.
+            int pf_front = p;
+            u32 pf = 0;
+            for (u32 i = start; i < end; i += 4) {
+                if (p - 256 < pf_front) {
+                    asm volatile("" ::"v"(pf));
+                    int a = pf_front - 128 * (int)(ql + 1);
+                    a = a < 0 ? 0 : a;
+                    pf = ld_u32_unaligned(stream + (a & ~3));
+                    pf_front -= 512;
+                }
+                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                o[i + ql] = val;
+            }
+            asm volatile("" ::"v"(pf));
         }
         if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
             for (u32 i = nfull; i < nb; i++) {
-                u32 val = dec_step<RFOLD>(st, p, ql == 3, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream);
+                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
                 if (ql == 3) o[i] = val;
             }
         }
     }
+}
+
+// ---- K8: one workgroup per block.  Loads the parsed table (coalesced), builds the
+// slot -> symbol table, stages the block's stream in LDS when it fits, then one quad of lanes
+// per segment decodes forward from its restart point.
+template <bool LDS_TAB, bool RFOLD>
+__global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
+    u32 max_ns, u32 stream_cap, u16* __restrict__ g_s2s, u32* __restrict__ g_cum,
+    const uint4* __restrict__ binfo, u32* __restrict__ gflags)
+{
+    extern __shared__ u8 smem[];
+    __shared__ u32 sh_bad;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 b = blockIdx.x;
+    const uint4 bi = binfo[b];
+    if (bi.w) return;  // parse error already flagged
+    const u32 ns = bi.x, logM = bi.y, rflag = bi.z;
+    const u32 nb = geo_block_n(g, b);
+    const u64 boff = block_off[b];
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const u32 f = g.f;
+    const u32 T = fold_T(f);
+    const u32 M = 1u << logM;
+    // LDS carve: [cum][s2s][most-frequent table][staged stream]
+    const u32 cb = ((max_ns + 2) * 4 + 15) & ~15u;
+    const u32 s2s_bytes = (u32)(((u64)maxM * 2 + 15) & ~15ull);
+    u32* gc = g_cum + (u64)b * (NSP + 8);
+    u32* cum;
+    u16* s2s;
+    u32* mfl = nullptr;
+    u32* lds_stream;
+    if (LDS_TAB) {
+        cum = (u32*)smem;
+        s2s = (u16*)(smem + cb);
+        u32 off = cb + s2s_bytes;
+        if (RFOLD) {
+            mfl = (u32*)(smem + off);
+            off += 4 * T;
+        }
+        lds_stream = (u32*)(smem + off);
+    } else {
+        cum = gc;
+        s2s = g_s2s + (u64)b * maxM;
+        u32 off = 0;
+        if (RFOLD) {
+            mfl = (u32*)smem;
+            off = 4 * T;
+        }
+        lds_stream = (u32*)(smem + off);
+    }
+    if (tid == 0) sh_bad = 0;
+    __syncthreads();
+    // inc[s] = sum_{t<=s} nfreq[t] + s  (ans_util.hpp:33-41)  ->  cum[s+1] = inc[s] - s
+    for (u32 s = tid; s < ns; s += nt) cum[s + 1] = gc[s + 1] - s;
+    if (tid == 0) cum[0] = 0;
+    if (RFOLD && rflag) {
+        for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
+    }
+    const bool st_lds = (sbytes + 24 <= stream_cap);
+    if (st_lds) {  // byte a of the stream -> LDS byte a + 8 (8 guard bytes in front)
+        const u32 nw = (sbytes + 3) >> 2;
+        for (u32 w = tid; w < nw; w += nt) lds_stream[w + 2] = ld_u32_unaligned(stream + 4 * (u64)w);
+        if (tid < 2) lds_stream[tid] = 0;
+        if (tid < 2) lds_stream[nw + 2 + tid] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    {  // validation: monotone and sums to M
+        u32 bad = 0;
+        for (u32 s = tid; s < ns; s += nt) bad |= (cum[s + 1] < cum[s]) ? 1u : 0u;
+        if (tid == 0 && cum[ns] != M) bad = 1;
+        if (bad) {
+            sh_bad = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+        }
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    {  // slot -> symbol table (the reference's table[M], ans_fold.hpp:190-204, 2 bytes per slot)
+        const u32 per = (M + nt - 1) / nt;
+        const u32 lo = tid * per;
+        u32 hi = lo + per;
+        hi = hi < M ? hi : M;
+        if (lo < M) {
+            u32 a = 0, z = ns;  // invariant cum[a] <= lo < cum[z]
+            while (z - a > 1) {
+                u32 mid = (a + z) >> 1;
+                if (cum[mid] <= lo) a = mid;
+                else z = mid;
+            }
+            u32 s = a;
+            for (u32 slot = lo; slot < hi; slot++) {
+                while (cum[s + 1] <= slot) s++;
+                s2s[slot] = (u16)s;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    u32* o = outp + (u64)b * g.block_ints;
+    if (st_lds)
+        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+    else
+        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
 }

@@ -206,7 +206,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if ((rc = ensure(c, c->sortSym, (size_t)NB * NSP * 2))) return rc;
     if ((rc = ensure(c, c->attS, (size_t)NB * ANSX_ATTEMPTS * NSP * 2))) return rc;
     if ((rc = ensure(c, c->prevS, (size_t)NB * NSP * 2))) return rc;
-    if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 8))) return rc;
+    if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 16))) return rc;
     if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
     if ((rc = ensure(c, c->table, (size_t)NB * NSP * sizeof(ansx_enc_entry)))) return rc;
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
@@ -249,10 +249,10 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     }
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 256, (size_t)NSP * 8 + 8192, s, g, NSP, hist,
         (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
-    const u32 nbatch = 3;
+    const u32 nbatch = 24 / ANSX_ATTEMPTS;  // frame sizes M0*2^t, t < 24 (t <= 16 suffices)
     for (u32 batch = 0; batch < nbatch; batch++) {
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
-            0, s, g, NSP, batch, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
+            0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
             (u16*)c->attS.p, (u32*)c->attMeta.p);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,

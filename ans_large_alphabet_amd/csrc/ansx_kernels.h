@@ -42,7 +42,7 @@ struct __attribute__((aligned(16))) ansx_enc_entry {
 };
 
 enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3 };
-enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
+enum { ANSX_ATTEMPTS = 4 };  // frame sizes tried per batch
 
 // ------------------------------------------------------------------------------------------
 // K1: folded-symbol histogram.  One workgroup per chunk of a block; LDS bins; coalesced 16 B
@@ -211,13 +211,17 @@ __global__ __launch_bounds__(256) void k_sort_entropy(ansx_geo g, u32 NSP,
 }
 
 // ------------------------------------------------------------------------------------------
-// K2b: scale_freqs (ans_util.hpp:77-95).  The recurrence over symbols is serial (each S
-// depends on the remaining frame), but different frame sizes M0*2^t are independent: one lane
-// per (block, t).  Doubles are evaluated exactly as written (no contraction).
+// K2b: scale_freqs (ans_util.hpp:77-95) + cross_entropy (util.hpp:284-298) for one candidate
+// frame size per LANE.  The recurrence over symbols is serial (each S depends on the remaining
+// frame), and the entropy sums must be taken left to right in index order to round like the
+// scalar reference, but different frame sizes M0*2^t and different blocks are independent: one
+// lane per (block, t), both loops in registers, inputs prefetched 8 symbols ahead.  Doubles
+// are evaluated exactly as written (the TU is built with -ffp-contract=off).
+// attMeta[(b,t)] = {ok, maxS, XH bits lo, XH bits hi}.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32 batch,
-    const u32* __restrict__ sortF, const u16* __restrict__ sortSym, const ansx_blk* __restrict__ blk,
-    u16* __restrict__ attS, u32* __restrict__ attMeta)
+    const u32* __restrict__ hist, const u32* __restrict__ sortF, const u16* __restrict__ sortSym,
+    const ansx_blk* __restrict__ blk, u16* __restrict__ attS, u32* __restrict__ attMeta)
 {
     const u32 gid = blockIdx.x * 256 + threadIdx.x;
     const u32 b = gid / ANSX_ATTEMPTS, t = gid % ANSX_ATTEMPTS;
@@ -226,48 +230,98 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     if (B.resolved) return;
     const u32 T = batch * ANSX_ATTEMPTS + t;
     const u32 sh = B.m0_log2 + T;
-    u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 2;
+    u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;
     if (sh > 31) {  // frame sizes beyond 2^31 are unreachable for valid inputs
         meta[0] = 0;
         meta[1] = 0;
         return;
     }
-    i64 M = (i64)1 << sh;
-    u64 fs = B.n;
+    // M and freq_sum are integers < 2^53: carried as doubles (exact), which keeps the
+    // int64/uint64 -> double conversions of ans_util.hpp:83 out of the dependency chain
+    double Md = (double)((i64)1 << sh);
+    double fsd = (double)B.n;
     const u32* F = sortF + (u64)b * NSP;
     const u16* Sy = sortSym + (u64)b * NSP;
     u16* S = attS + ((u64)b * ANSX_ATTEMPTS + t) * NSP;
     u32 maxS = 0;
     const u32 sigma = B.sigma;
-    for (u32 j = 0; j < sigma; j++) {  // evaluated as written: TU is built with -ffp-contract=off
-        u32 fr = F[j];
-        u32 sym = Sy[j];
-        double aratio = (double)M / (double)fs;
-        double v = aratio * (double)fr;
-        v = 0.5 + v;
-        u32 s = (u32)v;
-        if (s == 0) s = 1;
-        S[sym] = (u16)(s > 65535u ? 65535u : s);
-        maxS = s > maxS ? s : maxS;
-        M -= s;
-        fs -= fr;
-        if (M < 0) break;
+    bool stop = false;
+    // rows are 16-byte aligned and NSP (>= sigma rounded up to 8) entries long
+    uint4 fa = *(const uint4*)(F), fb = *(const uint4*)(F + 4), sy = *(const uint4*)(Sy);
+    for (u32 j0 = 0; j0 < sigma && !stop; j0 += 8) {
+        const u32 fr8[8] = { fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w };
+        const u32 sy8[8] = { sy.x & 0xFFFFu, sy.x >> 16, sy.y & 0xFFFFu, sy.y >> 16,
+            sy.z & 0xFFFFu, sy.z >> 16, sy.w & 0xFFFFu, sy.w >> 16 };
+        if (j0 + 8 < sigma) {  // next chunk in flight while this one is consumed
+            fa = *(const uint4*)(F + j0 + 8);
+            fb = *(const uint4*)(F + j0 + 12);
+            sy = *(const uint4*)(Sy + j0 + 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (!stop && j0 + u < sigma) {
+                const double frd = (double)fr8[u];
+                double aratio = Md / fsd;
+                double v = aratio * frd;
+                v = 0.5 + v;
+                u32 sc = (u32)v;
+                if (sc == 0) sc = 1;
+                S[sy8[u]] = (u16)(sc > 65535u ? 65535u : sc);
+                maxS = sc > maxS ? sc : maxS;
+                Md = Md - (double)sc;
+                fsd = fsd - frd;
+                if (Md < 0.0) stop = true;  // ans_util.hpp:90-91
+            }
+        }
     }
-    meta[0] = (M == 0) ? 1u : 0u;
+    const u32 ok = (Md == 0.0) ? 1u : 0u;
+    meta[0] = ok;
     meta[1] = maxS;
+    if (!ok || maxS >= ANSX_U16_LIMIT) return;  // failed, or the u16 exit: XH is not consulted
+    // cross entropy in index order (util.hpp:284-298); note the int accumulators there.
+    // Branch-free: an absent symbol contributes p = 0, q = 1 -> +0.0, which leaves the running
+    // sum unchanged (the sum is never -0.0), so the 8 log2 evaluations of a chunk overlap and
+    // only the final additions form the serial chain.
+    const u32 ns = B.max_sym + 1;
+    const u32* h = hist + (u64)b * NSP;
+    const double nd = (double)(int)B.n;
+    const double md = (double)(int)(1u << sh);
+    double acc = 0.0;
+    uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4), sv = *(const uint4*)(S);
+    for (u32 i0 = 0; i0 < ns; i0 += 8) {
+        const u32 h8[8] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w };
+        const u32 s8[8] = { sv.x & 0xFFFFu, sv.x >> 16, sv.y & 0xFFFFu, sv.y >> 16,
+            sv.z & 0xFFFFu, sv.z >> 16, sv.w & 0xFFFFu, sv.w >> 16 };
+        if (i0 + 8 < ns) {
+            ha = *(const uint4*)(h + i0 + 8);
+            hb = *(const uint4*)(h + i0 + 12);
+            sv = *(const uint4*)(S + i0 + 8);
+        }
+        double tm[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool valid = (i0 + u < ns) && (h8[u] != 0);
+            const double p = valid ? (double)h8[u] / nd : 0.0;
+            const double q = valid ? (double)s8[u] / md : 1.0;
+            tm[u] = p * ansx_log2_portable(q);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = acc + tm[u];
+    }
+    const u64 xb = ansx_f64_to_bits(-acc);
+    meta[2] = (u32)xb;
+    meta[3] = (u32)(xb >> 32);
 }
 
 // ------------------------------------------------------------------------------------------
-// K2c: stop rule of adjust_freqs (ans_util.hpp:127-153) + cross entropy (util.hpp:284-298)
-// + encoder table (ans_fold.hpp:82-91).  One wave per block.
+// K2c: stop rule of adjust_freqs (ans_util.hpp:127-153) over the batch's candidates, then the
+// encoder table (ans_fold.hpp:82-91).  One wave per block.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u16* __restrict__ attS, const u32* __restrict__ attMeta,
     u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
     u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch)
 {
-    __shared__ double terms[1024];
-    __shared__ int sh_flag;
     __shared__ u32 sh_part[64];
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
@@ -275,48 +329,19 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     if (B->resolved) return;
     const u32 ns = B->max_sym + 1;
     const u32* h = hist + (u64)b * NSP;
-    const double nd = (double)(int)B->n;  // util.hpp:288: accumulate into int
     const double thr = B->thr;
     int prev = B->prev;
     int chosen = -2;
     for (u32 t = 0; t < ANSX_ATTEMPTS; t++) {
-        const u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 2;
+        const u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;
         if (!meta[0]) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
         const u32 T = batch * ANSX_ATTEMPTS + t;
         if (meta[1] >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
             chosen = prev;
             break;
         }
-        const u16* S = attS + ((u64)b * ANSX_ATTEMPTS + t) * NSP;
-        const double md = (double)(int)(1u << (B->m0_log2 + T));
-        double acc = 0.0;
-        for (u32 base = 0; base < ns; base += 1024) {
-            __syncthreads();
-            for (u32 u = lane; u < 1024; u += 64) {
-                u32 i = base + u;
-                u32 fr = i < ns ? h[i] : 0u;
-                double tm = 1.0;
-                if (fr) {
-                    double p = (double)fr / nd;
-                    double q = (double)S[i] / md;
-                    tm = p * ansx_log2_portable(q);
-                }
-                terms[u] = tm;
-            }
-            __syncthreads();
-            if (lane == 0) {
-                u32 lim = ns - base < 1024 ? ns - base : 1024;
-                for (u32 u = 0; u < lim; u++) {
-                    double tm = terms[u];
-                    if (tm <= 0.0) acc = acc + tm;
-                }
-            }
-        }
-        if (lane == 0) sh_flag = ((-acc) < thr) ? 1 : 0;  // ans_util.hpp:149
-        __syncthreads();
-        int ok = sh_flag;
-        __syncthreads();
-        if (ok) {
+        const double XH = ansx_bits_to_f64((u64)meta[2] | ((u64)meta[3] << 32));
+        if (XH < thr) {  // ans_util.hpp:149
             chosen = (int)T;
             break;
         }
@@ -559,12 +584,17 @@ struct enc_lane {
     u32 p;  // byte cursor relative to the block's stream start (uniform within the quad)
 };
 
-// one symbol of one state.  x: value; (freq, base, rcp): its table entry, fetched ahead of the
-// dependency chain.
-__device__ __forceinline__ void enc_update(enc_lane& L, u32 x, u32 freq, u32 base, double rcp,
-    bool active, u32 ql, u32 f, u32 logM, u8* __restrict__ out)
+// one symbol of one state.  x: value (its exception-byte count k in e.k); e: its table entry,
+// fetched ahead of the dependency chain.
+struct enc_ent {
+    u32 freq, base, k;
+    double rcp;
+};
+
+__device__ __forceinline__ void enc_update(enc_lane& L, u32 x, const enc_ent e, bool active, u32 ql,
+    u32 logM, u8* __restrict__ out)
 {
-    const u32 k = fold_nbytes(f, x);
+    const u32 k = e.k, freq = e.freq;
     const u32 eb = x & ((1u << (8 * k)) - 1u);
     u64 st = L.st;
     // renormalise: state >= K*RADIX*freq  <=>  (state >> 36) >= freq   (ans_fold.hpp:105-110)
@@ -572,23 +602,23 @@ __device__ __forceinline__ void enc_update(enc_lane& L, u32 x, u32 freq, u32 bas
     const u32 w = (u32)st;
     if (rn) st >>= 32;
     // exact q = st / freq, r = st % freq; st < 2^36 * freq <= 2^52 (ans_fold.hpp:111).
-    // rcp is 1/freq to < 2^-40 relative, so trunc(st * rcp) is within +-1 of the quotient.
-    double qd = (double)st * rcp;
-    u64 q = (u64)qd;
-    i64 r = (i64)st - (i64)(q * (u64)freq);
-    if (r < 0) {
-        q -= 1;
-        r += freq;
-    } else if (r >= (i64)freq) {
-        q += 1;
-        r -= freq;
-    }
-    st = (q << logM) + (u64)r + (u64)base;
+    // rcp is 1/freq to < 2^-40 relative, so trunc(st * rcp) is within +-1 of the quotient;
+    // the remainder of the estimate lies in (-2^16, 2^17), so 32-bit arithmetic decides it.
+    const u32 st_hi = (u32)(st >> 32), st_lo = (u32)st;
+    const double std_ = __builtin_fma((double)st_hi, 4294967296.0, (double)st_lo);
+    const double qd = std_ * e.rcp;                             // < 2^36 + 1
+    const u32 q_hi = (u32)(qd * (1.0 / 4294967296.0));          // trunc
+    const u32 q_lo = (u32)__builtin_fma(-(double)q_hi, 4294967296.0, qd);
+    int r = (int)(st_lo - q_lo * freq);
+    const int adj = (r < 0) ? -1 : ((r >= (int)freq) ? 1 : 0);
+    r -= adj * (int)freq;
+    const u64 q = (((u64)q_hi << 32) | q_lo) + (u64)(i64)adj;
+    st = (q << logM) + (u64)((u32)r + e.base);
     if (active) L.st = st;
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
     u32 total;
     const u32 incl = quad_incl_scan(c, ql, &total);
-    u8* a = out + L.p + (incl - c);
+    u8* a = out + (L.p + (incl - c));
 #ifndef ANSX_ABL_NOSTORE
     if (active) {
         if (k == 1) a[0] = (u8)eb;
@@ -606,14 +636,11 @@ __device__ __forceinline__ void enc_update(enc_lane& L, u32 x, u32 freq, u32 bas
 template <bool LDS_TABLE> struct enc_tab;
 template <> struct enc_tab<false> {
     const ansx_enc_entry* t;
-    struct ent {
-        u32 freq, base;
-        double rcp;
-    };
-    __device__ __forceinline__ ent get(u32 sym) const
+    __device__ __forceinline__ enc_ent get(u32 f, u32 x) const
     {
-        ansx_enc_entry e = t[sym];
-        ent r;
+        enc_ent r;
+        r.k = fold_nbytes(f, x);
+        ansx_enc_entry e = t[fold_sym(f, x, r.k)];
         r.freq = e.freq;
         r.base = e.base;
         r.rcp = e.rcp;
@@ -622,14 +649,11 @@ template <> struct enc_tab<false> {
 };
 template <> struct enc_tab<true> {
     const u32* t;  // LDS
-    struct ent {
-        u32 freq, base;
-        double rcp;
-    };
-    __device__ __forceinline__ ent get(u32 sym) const
+    __device__ __forceinline__ enc_ent get(u32 f, u32 x) const
     {
-        const u32 e = t[sym];
-        ent r;
+        enc_ent r;
+        r.k = fold_nbytes(f, x);
+        const u32 e = t[fold_sym(f, x, r.k)];
         r.freq = e & 0xFFFFu;
         r.base = e >> 16;
         // 1/freq: hardware seed + one Newton step (relative error ~2^-50, far below the 2^-37
@@ -681,13 +705,11 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     enc_lane L;
     L.st = Lb;
     L.p = B->prelude_bytes;
-    auto lookup = [&](u32 x) { return tab.get(fold_sym(f, x, fold_nbytes(f, x))); };
     const u32 r = nb & 3;
     // tail symbols all go to state 0 (ans_fold.hpp:257-261)
     for (u32 t = 0; t < r; t++) {
         u32 x = src[nb - 1 - t];
-        auto e = lookup(x);
-        enc_update(L, x, e.freq, e.base, e.rcp, ql == 0, ql, f, logM, out);
+        enc_update(L, x, tab.get(f, x), ql == 0, ql, logM, out);
     }
     // groups of four, backwards (ans_fold.hpp:262-272): in[4g+3-q] -> state q
     const u32 G = nb >> 2;
@@ -710,21 +732,22 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     for (u32 t = G % ANSX_ENC_U; t > 0; t--) {
         const u32 gidx = --gi;
         u32 x = src[4 * gidx + 3 - ql];
-        auto e = lookup(x);
-        enc_update(L, x, e.freq, e.base, e.rcp, true, ql, f, logM, out);
+        enc_update(L, x, tab.get(f, x), true, ql, logM, out);
         record(gidx);
     }
     // software pipeline over batches of U groups: while batch t is encoded, the table entries
     // of batch t+1 and the inputs of batch t+2 are in flight, so the per-symbol dependency
     // chain (renorm test -> divide -> state) never waits on memory.
     if (gi) {
+        // restart points fall on batch boundaries when the interval is a multiple of U groups
+        const bool ck_per_batch = (cg % ANSX_ENC_U) == 0;
         const u32* base = src + 3 - ql;
         u32 x1[ANSX_ENC_U], x2[ANSX_ENC_U];
-        typename enc_tab<LDS_TABLE>::ent e1[ANSX_ENC_U];
+        enc_ent e1[ANSX_ENC_U];
 #pragma unroll
         for (int j = 0; j < ANSX_ENC_U; j++) x1[j] = base[4 * (gi - 1 - j)];
 #pragma unroll
-        for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = lookup(x1[j]);
+        for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, x1[j]);
         if (gi >= 2 * ANSX_ENC_U) {
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (gi - ANSX_ENC_U - 1 - j)];
@@ -734,7 +757,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         }
         while (gi) {
             u32 x0[ANSX_ENC_U];
-            typename enc_tab<LDS_TABLE>::ent e0[ANSX_ENC_U];
+            enc_ent e0[ANSX_ENC_U];
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_U; j++) {
                 x0[j] = x1[j];
@@ -744,16 +767,22 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
             const u32 top = gi;  // this batch encodes groups top-1 ... top-U
             if (top >= 2 * ANSX_ENC_U) {
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = lookup(x1[j]);
+                for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, x1[j]);
             }
             if (top >= 3 * ANSX_ENC_U) {
 #pragma unroll
                 for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (top - 2 * ANSX_ENC_U - 1 - j)];
             }
+            if (ck_per_batch) {
 #pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) {
-                enc_update(L, x0[j], e0[j].freq, e0[j].base, e0[j].rcp, true, ql, f, logM, out);
-                record(top - 1 - j);
+                for (int j = 0; j < ANSX_ENC_U; j++) enc_update(L, x0[j], e0[j], true, ql, logM, out);
+                record(top - ANSX_ENC_U);
+            } else {
+#pragma unroll
+                for (int j = 0; j < ANSX_ENC_U; j++) {
+                    enc_update(L, x0[j], e0[j], true, ql, logM, out);
+                    record(top - 1 - j);
+                }
             }
             gi = top - ANSX_ENC_U;
         }

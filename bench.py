@@ -152,34 +152,16 @@ def main():
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather_buf = None
-    sizes = None
+    from ans_large_alphabet_amd import dist as adist
 
     def step():
         nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
         works = []
         if dist is not None:
-            # concatenate the per-GPU containers on rank 0: sizes first, then one direct
-            # send per rank (each sender uses its own xGMI link to the root)
-            nonlocal gather_buf, sizes
-            mine = torch.tensor([nb], dtype=torch.int64, device=device)
-            if sizes is None:
-                sizes = torch.zeros(world, dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(sizes, mine)
-            if rank == 0:
-                sz = sizes.tolist()
-                total = sum(sz)
-                if gather_buf is None or gather_buf.numel() < total:
-                    gather_buf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=device)
-                off = sz[0]
-                ops = []
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, gather_buf[off:off + sz[r]], r))
-                    off += sz[r]
-                if ops:
-                    works = dist.batch_isend_irecv(ops)
-            else:
-                works = dist.batch_isend_irecv([dist.P2POp(dist.isend, d_out[:nb], 0)])
+            # concatenate the per-GPU containers on rank 0: 8-byte sizes first, then one direct
+            # send per rank (each sender uses its own xGMI link to the root); the transfer runs
+            # on RCCL's stream while this rank decodes its own container below
+            _buf, _sizes, works = adist.gather_containers(d_out, nb, dst=0, async_op=True)
         codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
         for w in works:
             w.wait()

@@ -1,0 +1,106 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/ansx.h declares; pure host functions behave; no compute call is made (no GPU here)."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import ans_large_alphabet_amd as A_
+
+    if not os.path.exists(os.path.join(ROOT, "ans_large_alphabet_amd", "libansx.so")):
+        A_.build_library()
+    return A_
+
+
+def test_every_declared_symbol_is_exported(A):
+    hdr = open(os.path.join(ROOT, "include", "ansx.h")).read()
+    declared = sorted(set(re.findall(r"\b(ansx_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 16
+    lib = C.CDLL(os.path.join(ROOT, "ans_large_alphabet_amd", "libansx.so"))
+    for name in declared:
+        assert hasattr(lib, name), name
+    from ans_large_alphabet_amd import _lib
+
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_names_follow_methods_hpp(A):
+    # /root/reference/include/methods.hpp:530-533,550-553
+    assert A.ANSfold(1).name() == "ANSfold-1"
+    assert A.ANSfold(5).name() == "ANSfold-5"
+    assert A.ANSrfold(3).name() == "ANSrfold-3"
+
+
+def test_bound_and_argument_validation(A):
+    L = A.lib()
+    for kind in (A.FOLD, A.RFOLD):
+        for f in (1, 3, 5):
+            b = L.ansx_bound(kind, f, 1 << 20, None)
+            assert b >= 7 * (1 << 20)
+    assert L.ansx_bound(A.FOLD, 0, 100, None) == 0      # fidelity out of range
+    assert L.ansx_bound(A.FOLD, 8, 100, None) == 0
+    assert L.ansx_bound(2, 1, 100, None) == 0           # unknown codec
+    assert L.ansx_bound(A.FOLD, 1, 0, None) == 0        # n == 0 (reference never terminates)
+    o = A.make_opts(block_ints=1001)                    # blocks must be a multiple of 4 ints
+    assert L.ansx_bound(A.FOLD, 1, 100, C.byref(o)) == 0
+    o = A.make_opts(block_ints=A.SINGLE_STREAM)
+    assert L.ansx_bound(A.FOLD, 1, 100, C.byref(o)) >= 700
+    for st in range(8):
+        assert L.ansx_strerror(st)
+
+
+def test_container_info_rejects_garbage(A):
+    from ans_large_alphabet_amd import _lib
+
+    H = _lib.ContainerHeader()
+    buf = np.zeros(128, dtype=np.uint8)
+    assert A.lib().ansx_container_info(buf.ctypes.data, buf.size, C.byref(H)) == _lib.ERR_FORMAT
+    assert A.lib().ansx_container_info(buf.ctypes.data, 10, C.byref(H)) == _lib.ERR_FORMAT
+
+
+def test_init_without_device_fails_loudly(A):
+    """No GPU in the CPU container: the product must refuse, not fall back."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(A.AnsxError) as ei:
+        A.Context()
+    assert ei.value.status == 5  # ANSX_ERR_NO_DEVICE
+
+
+def test_portable_log2_close_to_libm(A):
+    """The device normaliser's log2 (same code on host) is within 1 ulp of libm and exact on
+    powers of two (normalisation)."""
+    L = A.lib()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    xs = np.concatenate([rng.random(20000), rng.integers(1, 65535, 20000) / 65536.0,
+                         rng.integers(1, 1 << 14, 20000) / float(1 << 14)])
+    for x in xs:
+        if x <= 0:
+            continue
+        a, b = L.ansx_host_log2(float(x)), math.log2(float(x))
+        if b != 0:
+            worst = max(worst, abs(a - b) / abs(b))
+    assert worst <= 2.3e-16
+    for k in range(-40, 20):
+        assert L.ansx_host_log2(2.0 ** k) == float(k)
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must not reference the test oracle."""
+    pkg = os.path.join(ROOT, "ans_large_alphabet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle_lib" not in txt and "ans_oracle" not in txt and "libans_ref" not in txt, fn

@@ -260,3 +260,38 @@ def test_full_size_roundtrip_properties(A, ctx):
         assert np.array_equal(parts["ckpt_state"][b][:st.shape[0]], st)
     bpi = 8.0 * nb / n
     assert 8.0 < bpi < 9.6
+
+
+def test_whole_container_equals_python_builder(A, ctx):
+    """Header, block index, restart points and payload — the complete container — against an
+    independent Python assembly of oracle block streams (tests/container_py.py)."""
+    import container_py as cp
+
+    for kind, f, block, ck, n in ((ol.FOLD, 1, 4096, 1024, 20001), (ol.RFOLD, 3, 4096, 512, 9999),
+                                  (ol.FOLD, 5, 16384, 4096, 40000)):
+        data = ol.gen_inputs("zipf20s1.2", n, seed=n)
+        codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ck)
+        got = codec.encode(data)
+        exp = cp.build_container(kind, f, data, block, ck)
+        assert got.size == exp.size and np.array_equal(got, exp), (kind, f)
+
+
+def test_rank_shards_merge_into_one_decodable_container(A, ctx):
+    """Multi-GPU data path on one device: encode two contiguous block ranges separately (what
+    two ranks do), merge on the 'root' (index rebase), decode the merged container as a whole."""
+    torch = pytest.importorskip("torch")
+    from ans_large_alphabet_amd import dist as adist
+
+    n, block = 200003, 16384
+    data = ol.gen_inputs("zipf20s1.2", n, seed=8)
+    codec = codec_for(A, ctx, ol.FOLD, 1, block_ints=block, ckpt_interval=1024)
+    parts, sizes = [], []
+    for r in range(2):
+        lo, cnt = adist.shard_blocks(n, block, r, 2)
+        c = codec.encode(data[lo:lo + cnt])
+        parts.append(torch.from_numpy(c.copy()))
+        sizes.append(c.size)
+    merged = adist.merge_containers(torch.cat(parts), sizes).numpy()
+    whole = codec.encode(data)
+    assert np.array_equal(merged, whole)
+    assert np.array_equal(codec.decode(merged, n), data)

@@ -220,6 +220,9 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
     HIPCHK(c, hipMemsetAsync(blk, 0, (size_t)NB * sizeof(ansx_blk), s));
+    // header / index / restart-point area: unused slots (short last block) and alignment
+    // padding are defined to be zero, so equal inputs give byte-identical containers
+    if (!P.plain) HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
 
     const u32* src = d_in;
     const u32* mostfreq = nullptr;

@@ -252,27 +252,32 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     }
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 256, (size_t)NSP * 8 + 8192, s, g, NSP, hist,
         (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
-    const u32 nbatch = 24 / ANSX_ATTEMPTS;  // frame sizes M0*2^t, t < 24 (t <= 16 suffices)
+    // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
+    // first batch; the count of undecided blocks comes back with the words the encoder launch
+    // needs anyway (largest alphabet / frame), so further batches are launched only on demand.
+    const u32 nbatch = 24 / ANSX_ATTEMPTS;  // t < 24 (t <= 16 suffices)
+    u32 max_logM = 0, max_ns = 0;
     for (u32 batch = 0; batch < nbatch; batch++) {
+        if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
             0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
             (u16*)c->attS.p, (u32*)c->attMeta.p);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
             (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);
+        HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        int st0 = flags_to_status(c->h_pin[ANSX_G_ERR]);
+        if (st0) return st0;
+        max_logM = c->h_pin[ANSX_G_MAXLOGM];
+        max_ns = c->h_pin[ANSX_G_MAXNSYMS];
+        if (c->h_pin[ANSX_G_PAD] == 0) break;
     }
     // K3
     LAUNCH(c, "k_write_prelude", k_write_prelude, NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
         (const ansx_enc_entry*)c->table.p, hist, blk, (u8*)c->scratch.p, (u64)scr_stride, mostfreq);
-    // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit; their size depends on
-    // the largest alphabet / frame actually produced, so read those two words back first.
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    {
-        int st0 = flags_to_status(c->h_pin[ANSX_G_ERR]);
-        if (st0) return st0;
-    }
-    const u32 max_logM = c->h_pin[ANSX_G_MAXLOGM], max_ns = c->h_pin[ANSX_G_MAXNSYMS];
+    // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
+    // alphabet / frame actually produced, read back above).
     u64* ck_state = P.plain ? nullptr : (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = P.plain ? nullptr : (u32*)(d_out + P.lay.ckoff_off);
     const u32 lds_stride = max_ns | 1u;  // odd stride spreads the 16 tables over the banks
@@ -378,7 +383,8 @@ __global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 p
     if (i == 0 && a != 0) bad = true;
     if (i == g.nblocks - 1 && b != payload_bytes) bad = true;
     if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
-    else atomicMax(&gflags[ANSX_G_PAD], (u32)(b - a));  // largest block stream (sizes the LDS staging)
+    else if (__hip_atomic_load(&gflags[ANSX_G_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)(b - a))
+        atomicMax(&gflags[ANSX_G_PAD], (u32)(b - a));  // largest block stream (sizes the LDS staging)
 }
 
 int parse_header(const u8* h, size_t bytes, ansx_container_header* out)

@@ -322,7 +322,6 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
     u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch)
 {
-    __shared__ u32 sh_part[64];
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
@@ -356,6 +355,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         }
         if (lane == 0) {
             B->prev = prev;
+            atomicAdd(&gflags[ANSX_G_PAD], 1u);  // encode: blocks still undecided after this batch
             if (last_batch) {
                 B->resolved = 1;
                 B->status = 7;  // ANSX_ERR_MODEL
@@ -376,33 +376,43 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     const u16* S = (chosen >= (int)(batch * ANSX_ATTEMPTS))
         ? attS + ((u64)b * ANSX_ATTEMPTS + (chosen - batch * ANSX_ATTEMPTS)) * NSP
         : prevS + (u64)b * NSP;
-    // exclusive scan of the chosen frequencies -> encoder table (ans_fold.hpp:82-91)
-    const u32 per = (ns + 63) / 64;
-    const u32 lo = lane * per, hi = (lo + per) < ns ? (lo + per) : ns;
-    u32 sum = 0;
-    for (u32 s = lo; s < hi; s++) sum += h[s] ? (u32)S[s] : 0u;
-    sh_part[lane] = sum;
-    __syncthreads();
-    u32 run = 0;
-    for (u32 l = 0; l < lane; l++) run += sh_part[l];
+    // exclusive scan of the chosen frequencies -> encoder table (ans_fold.hpp:82-91):
+    // lane = symbol, 64 symbols per pass (coalesced), wave prefix sum, carry between passes
     ansx_enc_entry* tab = table + (u64)b * NSP;
     u32* t32 = tab32 + (u64)b * NSP;
-    for (u32 s = lo; s < hi; s++) {
-        u32 fr = h[s] ? (u32)S[s] : 0u;
-        ansx_enc_entry e;
-        e.base = run;
-        e.freq = fr;
-        e.rcp = fr ? 1.0 / (double)fr : 0.0;
-        tab[s] = e;
-        t32[s] = (run << 16) | fr;  // valid while M <= 65536 (base < 2^16, freq < 65535)
-        run += fr;
+    u32 carry = 0;
+    for (u32 s0 = 0; s0 < ns; s0 += 64) {
+        const u32 s = s0 + lane;
+        const u32 hv = s < ns ? h[s] : 0u;
+        const u32 sv = s < ns ? (u32)S[s] : 0u;
+        const u32 fr = hv ? sv : 0u;
+        u32 incl = fr;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        const u32 base = carry + incl - fr;
+        if (s < ns) {
+            ansx_enc_entry e;
+            e.base = base;
+            e.freq = fr;
+            e.rcp = fr ? 1.0 / (double)fr : 0.0;
+            tab[s] = e;
+            t32[s] = (base << 16) | fr;  // valid while M <= 65536 (base < 2^16, freq < 65535)
+        }
+        carry += __shfl(incl, 63);
     }
     if (lane == 0) {
         u32 logM = B->m0_log2 + (u32)chosen;
         B->logM = logM;
         B->resolved = 1;
-        atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
-        atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+        // same-address atomics serialise in L2 (16 K blocks): only the few blocks that raise the
+        // running maximum issue one
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXLOGM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < logM)
+            atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
+            atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
     }
 }
 

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -243,14 +244,16 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if (cpb > 1) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)NB * NSP * 4, s));
     LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * 4, s, src, g, chunk, cpb, NSP,
         hist, blk, gflags, 1u << 30);
-    // K2
-    if ((size_t)NSP * 8 + 8192 > 48 * 1024) {
+    // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
+    const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
+    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4;
+    if (k2a_lds > 32 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 8192)));
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
+    if ((size_t)NSP * 8 + 64 > 48 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
-    }
-    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 256, (size_t)NSP * 8 + 8192, s, g, NSP, hist,
+    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, hist,
         (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch

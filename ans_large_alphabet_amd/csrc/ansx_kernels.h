@@ -107,92 +107,142 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 }
 
 // ------------------------------------------------------------------------------------------
-// K2a: sort the non-zero (freq, sym) pairs ascending (ans_util.hpp:114-122) with an LDS bitonic
-// network, and evaluate the entropy H in index order (util.hpp:271-282): the p*log2(p) terms
-// are computed lane-parallel, the sum is taken serially so that its rounding matches a scalar
-// left-to-right accumulation.
+// K2a: order the non-zero (freq, sym) pairs ascending (ans_util.hpp:114-122) and evaluate the
+// entropy H (util.hpp:271-282).  One wave per block.
+//
+// The order is a STABLE sort by frequency of symbols that are already in index order, and the
+// frequencies of a block are mostly tiny, so it is done as a counting sort: frequencies below
+// ANSX_VMAX are binned in LDS; within a 64-symbol pass the lanes that share a frequency are found
+// with ballots (rank = popcount of the matching lanes below), and the running per-value cursor
+// carries the order across passes.  The few symbols with freq >= ANSX_VMAX ("big", at most
+// n/ANSX_VMAX of them) are ranked among themselves and appended.
+// Entropy: p*log2(p) terms lane-parallel, summed serially in index order so that the rounding
+// matches a scalar left-to-right accumulation.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sort_entropy(ansx_geo g, u32 NSP,
+#define ANSX_VMAX 2048u
+
+__global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk)
 {
-    extern __shared__ u64 lds64[];
-    __shared__ u32 sh_sigma;
-    __shared__ unsigned long long sh_total;
-    const u32 tid = threadIdx.x;
+    extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
+    __shared__ u32 cnt[ANSX_VMAX];
+    __shared__ double terms[512];
+    __shared__ u32 sh_nbig;
+    u64* big_keys = lds_k2a;
+    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [ns] this block's histogram row
+    const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const u32 ns = blk[b].max_sym + 1;
-    u32 N2 = 2;
-    while (N2 < ns) N2 <<= 1;
-    u64* keys = lds64;
-    double* terms = (double*)(lds64 + N2);
     const u32* h = hist + (u64)b * NSP;
-    if (tid == 0) {
-        sh_sigma = 0;
-        sh_total = 0;
-    }
-    __syncthreads();
-    u32 lsig = 0;
-    u64 ltot = 0;
-    for (u32 s = tid; s < N2; s += 256) {
-        u32 fr = s < ns ? h[s] : 0u;
-        keys[s] = fr ? (((u64)fr << 16) | s) : ~0ull;
-        lsig += fr ? 1u : 0u;
-        ltot += fr;
-    }
-    atomicAdd(&sh_sigma, lsig);
-    atomicAdd(&sh_total, (unsigned long long)ltot);
-    __syncthreads();
-    for (u32 k = 2; k <= N2; k <<= 1) {
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < N2; i += 256) {
-                u32 ixj = i ^ j;
-                if (ixj > i) {
-                    bool asc = (i & k) == 0;
-                    u64 x = keys[i], y = keys[ixj];
-                    if ((x > y) == asc) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const u32 sigma = sh_sigma;
-    const u64 total = sh_total;
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
-    for (u32 j = tid; j < sigma; j += 256) {
-        u64 kx = keys[j];
-        oF[j] = (u32)(kx >> 16);
-        oS[j] = (u16)(kx & 0xFFFFu);
+    // stage the histogram row once (coalesced, all loads in flight together)
+    for (u32 s = lane; s < ns; s += 64) hrow[s] = h[s];
+    for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
+    if (lane == 0) sh_nbig = 0;
+    __syncthreads();
+    // pass 1: bin the frequencies
+    u32 sigma = 0;
+    u64 total = 0;
+    for (u32 s0 = 0; s0 < ns; s0 += 64) {
+        const u32 s = s0 + lane;
+        const u32 fr = s < ns ? hrow[s] : 0u;
+        if (fr) {
+            sigma++;
+            total += fr;
+            if (fr < ANSX_VMAX) atomicAdd(&cnt[fr], 1u);
+            else {
+                const u32 slot = atomicAdd(&sh_nbig, 1u);
+                if (slot < nbig_cap) big_keys[slot] = ((u64)fr << 16) | s;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sigma += __shfl_xor(sigma, o);
+        total += __shfl_xor(total, o);
+    }
+    __syncthreads();
+    // pass 2: exclusive scan of the bins -> first output position of every frequency value
+    u32 nsmall;
+    {
+        const u32 per = ANSX_VMAX / 64;
+        u32 loc = 0;
+        for (u32 i = 0; i < per; i++) loc += cnt[lane * per + i];
+        u32 incl = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 t = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += t;
+        }
+        nsmall = __shfl(incl, 63);
+        u32 run = incl - loc;
+        for (u32 i = 0; i < per; i++) {
+            u32 t = cnt[lane * per + i];
+            cnt[lane * per + i] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+    // pass 3: stable placement, 64 symbols at a time in index order
+    for (u32 s0 = 0; s0 < ns; s0 += 64) {
+        const u32 s = s0 + lane;
+        const u32 fr = s < ns ? hrow[s] : 0u;
+        const bool small = fr != 0 && fr < ANSX_VMAX;
+        unsigned long long todo = __ballot(small);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const u32 v0 = (u32)__builtin_amdgcn_readlane((int)fr, leader);  // leader is wave-uniform
+            const unsigned long long m = __ballot(small && fr == v0);
+            if (small && fr == v0) {
+                const u32 pos = cnt[v0] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                oF[pos] = fr;
+                oS[pos] = (u16)s;
+            }
+            // one wave: LDS operations execute in program order, so the cursor update below
+            // follows the reads above without a barrier (a barrier here would also drain the
+            // outstanding global stores on every iteration)
+            if ((int)lane == leader) cnt[v0] += (u32)__popcll(m);
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    // big symbols: rank among themselves by (freq, sym)
+    const u32 nbig = sh_nbig < nbig_cap ? sh_nbig : nbig_cap;
+    for (u32 i = lane; i < nbig; i += 64) {
+        const u64 key = big_keys[i];
+        u32 rank = 0;
+        for (u32 j = 0; j < nbig; j++) rank += (big_keys[j] < key) ? 1u : 0u;
+        oF[nsmall + rank] = (u32)(key >> 16);
+        oS[nsmall + rank] = (u16)(key & 0xFFFFu);
     }
     // entropy, util.hpp:271-282
     const double nd = (double)total;
     double acc = 0.0;
-    for (u32 base = 0; base < ns; base += 1024) {
+    for (u32 base = 0; base < ns; base += 512) {
         __syncthreads();
-        for (u32 u = tid; u < 1024; u += 256) {
+        for (u32 u = lane; u < 512; u += 64) {
             u32 i = base + u;
-            u32 fr = i < ns ? h[i] : 0u;
-            double t = 1.0;  // marker: absent (real terms are <= 0)
-            if (fr) {
-                double p = (double)fr / nd;
-                t = p * ansx_log2_portable(p);
-            }
-            terms[u] = t;
+            u32 fr = i < ns ? hrow[i] : 0u;
+            // an absent symbol adds p*log2(1) = +0.0: the sum (never -0.0) is unchanged
+            double p = fr ? (double)fr / nd : 0.0;
+            double q = fr ? p : 1.0;
+            terms[u] = p * ansx_log2_portable(q);
         }
         __syncthreads();
-        if (tid == 0) {
-            u32 lim = ns - base < 1024 ? ns - base : 1024;
-            for (u32 u = 0; u < lim; u++) {
-                double t = terms[u];
-                if (t <= 0.0) acc = acc + t;
+        if (lane == 0) {
+            u32 lim = ns - base < 512 ? ns - base : 512;
+            u32 u = 0;
+            for (; u + 4 <= lim; u += 4) {
+                acc = acc + terms[u];
+                acc = acc + terms[u + 1];
+                acc = acc + terms[u + 2];
+                acc = acc + terms[u + 3];
             }
+            for (; u < lim; u++) acc = acc + terms[u];
         }
     }
-    if (tid == 0) {
+    if (lane == 0) {
         double H = -acc;
         double approx = 1.0 + (double)1 / (double)1000;  // ans_util.hpp:124
         u32 m0 = 0;  // ans_util.hpp:109-112

@@ -322,17 +322,9 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     int rc;
     if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
     if ((rc = ensure(c, c->dec_info, (size_t)g.nblocks * 16))) return rc;
-    // K7: one lane per block, bpw blocks per wave, preludes staged in LDS
-    const u32 pw = (u32)rup(max_ns + 12, 4);  // words per staged prelude (<= 32 bits per item)
-    u32 bpw = 16;
-    while (bpw > 1 && (size_t)bpw * pw * 4 > 96 * 1024) bpw >>= 1;
-    const size_t plds = (size_t)bpw * pw * 4;
-    if (plds > 150 * 1024) return ANSX_ERR_FORMAT;
-    if (plds > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude<RF>,
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-    LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + bpw - 1) / bpw, 64, plds, s, cont, g, NSP,
-        boff, payload_off, max_ns, maxM, bpw, pw, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    // K7: one lane per block, 64 blocks per wave
+    LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
+        boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
     // K8
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
     u32 threads = (u32)rup((size_t)nseg * 4, 64);

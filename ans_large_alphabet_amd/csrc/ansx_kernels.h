@@ -944,133 +944,118 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
 // Tables live in LDS (LDS_TAB) or, for very large frames, in a global workspace.
 // ------------------------------------------------------------------------------------------
 // ---- K7: prelude parse.  Bit parsing of the interpolative code is serial per block, so blocks
-// are spread over LANES: each wave stages the preludes of `bpw` blocks in LDS (coalesced
-// copies) and lanes 0..bpw-1 each walk one of them (interp.hpp:47-63,81-97; vbyte.hpp:82-95;
-// ans_util.hpp:25-42).  Output per block: inc[] in the global table row (cum[s+1] = inc[s],
-// un-prefix-summed later) and {nsyms, log2 M, rfold flag, error}.
+// are spread over LANES: every lane of a wave walks one block's prelude (interp.hpp:47-63,81-97;
+// vbyte.hpp:82-95; ans_util.hpp:25-42).  The bit stream is read through a 128-bit register
+// window refilled by unaligned 8-byte global loads issued one refill ahead; the traversal stack
+// lives in LDS with one 16-byte entry per pending right subtree.  Output per block: inc[] in
+// the global table row (cum[s+1] = inc[s], un-prefix-summed by k_decode) and
+// {nsyms, log2 M, rfold flag, error}.
 template <bool RFOLD>
 __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
-    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, u32 bpw, u32 pw,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
     u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
 {
-    extern __shared__ u32 lds_pre[];  // bpw x pw words
-    __shared__ u32 sh_ipos[16], sh_ns[16], sh_sb[16];
-    __shared__ u32 stk[16][4 * 20];
+    __shared__ uint4 stk[20][64];  // [depth][lane]: conflict-free 16-byte accesses
     const u32 lane = threadIdx.x;
     const u32 T = fold_T(g.f);
-    const u32 b0 = blockIdx.x * bpw;
-    u32 err = 0, ns = 0, logM = 0, flag = 0, ipos = 0, sbytes = 0;
-    const u32 b = b0 + lane;
-    const bool mine = lane < bpw && b < g.nblocks;
-    if (mine) {
-        const u64 boff = block_off[b];
-        const u8* stream = cont + payload_off + boff;
-        sbytes = (u32)(block_off[b + 1] - boff);
-        u32 pos = 0;
-        if (RFOLD) {  // ans_reorder_fold.hpp:238-254
-            flag = ld_u32_unaligned(stream);
-            pos = 4 + (flag == 1 ? 4 * T : 0);
-            if (flag > 1) err = 1;
-        }
-        u32 ms = 0, shv = 0;  // vbyte (vbyte.hpp:82-95)
-        if (!err && sbytes >= pos + 38) {
-            for (int i = 0; i < 5; i++) {
-                u8 cbyte = stream[pos++];
-                ms += (u32)(cbyte & 127) << shv;
-                if (!(cbyte & 128)) break;
-                shv += 7;
-            }
-            logM = stream[pos++];
-        } else {
-            err = 1;
-        }
-        ns = ms + 1;
-        if (ns > max_ns || ns > NSP || logM > 31 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
-        ipos = pos;
+    const u32 b = blockIdx.x * 64 + lane;
+    if (b >= g.nblocks) return;
+    u32 err = 0, ns = 0, logM = 0, flag = 0;
+    const u64 boff = block_off[b];
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    u32 pos = 0;
+    if (RFOLD) {  // ans_reorder_fold.hpp:238-254
+        flag = ld_u32_unaligned(stream);
+        pos = 4 + (flag == 1 ? 4 * T : 0);
+        if (flag > 1) err = 1;
     }
-    if (lane < 16) {
-        sh_ipos[lane] = ipos;
-        sh_ns[lane] = (mine && !err) ? ns : 0;
-        sh_sb[lane] = sbytes;
-    }
-    __syncthreads();
-    // stage the interpolative words of every block of this wave
-    for (u32 j = 0; j < bpw; j++) {
-        const u32 nsj = sh_ns[j];
-        if (nsj == 0) continue;
-        const u64 boff = block_off[b0 + j];
-        const u8* sj = cont + payload_off + boff + sh_ipos[j];
-        u32 want = 4 * nsj + 16, avail = sh_sb[j] - sh_ipos[j];
-        u32 nbytes = want < avail ? want : avail;
-        u32 nw = (nbytes + 3) >> 2;
-        if (nw > pw - 2) nw = pw - 2;
-        u32* dst = lds_pre + j * pw;
-        for (u32 w = lane; w < nw; w += 64) dst[w] = ld_u32_unaligned(sj + 4 * (u64)w);
-        if (lane == 0) {
-            dst[nw] = 0;
-            dst[nw + 1] = 0;
+    u32 ms = 0, shv = 0;  // vbyte (vbyte.hpp:82-95)
+    if (!err && sbytes >= pos + 38) {
+        for (int i = 0; i < 5; i++) {
+            u8 cbyte = stream[pos++];
+            ms += (u32)(cbyte & 127) << shv;
+            if (!(cbyte & 128)) break;
+            shv += 7;
         }
+        logM = stream[pos++];
+    } else {
+        err = 1;
     }
-    __syncthreads();
-    if (mine && !err) {
-        const u32* pre = lds_pre + lane * pw;
+    ns = ms + 1;
+    if (ns > max_ns || ns > NSP || logM > 30 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
+    if (!err) {
+        const u8* bp = stream + pos;  // interpolative words start here
         u32* cum = g_cum + (u64)b * (NSP + 8);
-        u32* st = stk[lane];
-        u32 bitpos = 0;
-        const u32 maxbits = (sbytes - ipos) * 8;
-        auto getbits = [&](u32 nbits) -> u32 {
+        // 128-bit window: w0 = bits [base, base+64), w1 = next 64 bits (already in flight)
+        u64 w0 = ld_u64_unaligned(bp), w1 = ld_u64_unaligned(bp + 8);
+        u32 consumed = 0;          // bits of w0 already used
+        u32 next_byte = 16;        // offset of the next refill
+        u32 total_bits = 0;
+        const u32 maxbits = (sbytes - pos) * 8;
+        auto getbits = [&](u32 nbits) -> u32 {  // nbits in [0, 32]
             if (nbits == 0) return 0u;
-            const u32 wi = bitpos >> 5, sh = bitpos & 31;
-            const u64 two = (u64)pre[wi] | ((u64)pre[wi + 1] << 32);
-            bitpos += nbits;
-            return (u32)((two >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
+            u64 v = w0 >> consumed;
+            if (consumed + nbits > 64) v |= w1 << (64 - consumed);
+            consumed += nbits;
+            total_bits += nbits;
+            if (consumed >= 64) {
+                consumed -= 64;
+                w0 = w1;
+                w1 = ld_u64_unaligned(bp + next_byte);  // the stream continues behind the prelude
+                next_byte += 8;
+            }
+            return (u32)(v & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
         };
-        const u64 u = ((u64)1 << logM) + ns + 1;
-        u32 sp = 1;
-        st[0] = 0;
-        st[1] = ns;
-        st[2] = 1;
-        st[3] = (u32)(u + 1);
-        while (sp > 0 && !err) {
-            sp--;
-            u32 a = st[4 * sp], n = st[4 * sp + 1];
-            u64 low = st[4 * sp + 2], high = st[4 * sp + 3];
-            while (n > 0) {
-                const u32 h = (n + 1) >> 1;
-                const u64 n1 = h - 1, n2 = n - h;
-                const u64 U = high - n2 - low - n1 + 1;
-                if ((i64)U < 1 || bitpos > maxbits) {
+        // One item per iteration for every lane (no nested pop/descend loops, so lanes stay
+        // convergent): if the current range is empty, pop the pending right subtree; decode the
+        // range's middle item; push its right subtree; continue into the left one.
+        // All quantities fit 32 bits: u + 1 = M + nsyms + 2 < 2^31 (M <= 2^30 enforced above).
+        const u32 u = (1u << logM) + ns + 1;
+        u32 sp = 0;
+        u32 a = 0, n = ns, low = 1, high = u + 1;
+        for (u32 it = 0; it < ns; it++) {
+            if (n == 0) {  // a right subtree is always pending here (ns items in total)
+                if (sp == 0) {
                     err = 1;
                     break;
                 }
-                u64 val = 1;  // read_center_mid (interp.hpp:47-63)
-                const u32 bb = (U == 1) ? 0u : (64 - __clzll((unsigned long long)(U - 1)));
-                const u64 d = 2ull * U - (1ull << bb);
-                if (U != 1) {
-                    const u64 m = (1ull << bb) - U;
-                    val = (u64)getbits(bb - 1) + 1;
-                    if (val > m) val = (2ull * val + getbits(1)) - m - 1ull;
-                }
-                val = val + (d >> 1);
-                if (val > U) val -= U;
-                const u64 v = low + n1 - 1ull + val;
-                cum[a + h] = (u32)(v - 1);  // inc[a+h-1]
-                if (n2) {
-                    st[4 * sp] = a + h;
-                    st[4 * sp + 1] = (u32)n2;
-                    st[4 * sp + 2] = (u32)(v + 1);
-                    st[4 * sp + 3] = (u32)high;
-                    sp++;
-                }
-                n = (u32)n1;
-                high = v - 1;
+                sp--;
+                const uint4 e = stk[sp][lane];
+                a = e.x;
+                n = e.y;
+                low = e.z;
+                high = e.w;
             }
+            const u32 h = (n + 1) >> 1;
+            const u32 n1 = h - 1, n2 = n - h;
+            const u32 U = high - n2 - low - n1 + 1;
+            if (U == 0 || U > u + 1 || total_bits > maxbits) {
+                err = 1;
+                break;
+            }
+            u32 val = 1;  // read_center_mid (interp.hpp:47-63)
+            if (U != 1) {
+                const u32 bb = 32 - __clz(U - 1);       // hi(U-1)+1
+                const u32 m = (u32)((1ull << bb) - U);
+                const u32 dh = U - (1u << (bb - 1));    // (2U - 2^bb) >> 1
+                val = getbits(bb - 1) + 1;
+                if (val > m) val = (2 * val + getbits(1)) - m - 1;
+                val += dh;
+                if (val > U) val -= U;
+            }
+            const u32 v = low + n1 - 1 + val;
+            cum[a + h] = v - 1;  // inc[a+h-1]
+            if (n2) {
+                stk[sp][lane] = make_uint4(a + h, n2, v + 1, high);
+                sp++;
+            }
+            n = n1;
+            high = v - 1;
         }
     }
-    if (mine) {
-        binfo[b] = make_uint4(ns, logM, flag, err);
-        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
-    }
+    binfo[b] = make_uint4(ns, logM, flag, err);
+    if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
 }
 
 // 8 stream bytes ending at byte offset `end` (exclusive): from the LDS-staged copy (aligned

@@ -147,7 +147,7 @@ def main():
         d_in = gen_uniform(torch, n, 1, 256, 1234 + rank, device)
     else:
         raise SystemExit("unknown --dist")
-    cap = min(codec.bound(n), 3 * n + (64 << 20))
+    cap = min(codec.bound(n), 8 * n + (64 << 20))
     d_out = torch.empty(cap, dtype=torch.uint8, device=device)
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream

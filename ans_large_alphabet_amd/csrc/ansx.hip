@@ -181,14 +181,22 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
     ansx_blk* blk, u32* gflags, hipStream_t s)
 {
     if (g.block_ints > 16384u) return ANSX_ERR_ARG;
+    const u32 T = fold_T(g.f);
+    if (T <= 4096) {  // hash-table form
+        size_t lds = 6 * (size_t)ANSX_RF_SLOTS + 8 * (size_t)(T < 512 ? 512 : T);  // also holds a 1024-bin histogram
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash, g.nblocks, 256, lds, s, d_in, g, mapped, mostfreq,
+            blk, gflags);
+        return ANSX_OK;
+    }
     u32 N2 = 2;
     while (N2 < g.block_ints) N2 <<= 1;
-    const u32 T = fold_T(g.f);
     size_t lds = 6 * (size_t)N2 + 8 * (size_t)T + 16;
     if (lds > 48 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LAUNCH(c, "k_rfold_remap", k_rfold_remap, g.nblocks, 256, lds, s, d_in, g, N2, mapped, mostfreq,
+    LAUNCH(c, "k_rfold_remap_sort", k_rfold_remap, g.nblocks, 256, lds, s, d_in, g, N2, mapped, mostfreq,
         blk, gflags);
     return ANSX_OK;
 }

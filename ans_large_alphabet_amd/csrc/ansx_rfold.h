@@ -170,3 +170,201 @@ __global__ __launch_bounds__(256) void k_rfold_remap(const u32* __restrict__ in,
     }
     if (tid == 0) blk[b].flag = 1;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// K9 (fast form, T <= 4096): the same selection without sorting the block.  Distinct values and
+// their counts are collected in an LDS open-addressing hash table; the count threshold c* and,
+// among the values with count == c*, the value threshold v* are found by bisection over the
+// table; only the T selected (count, value) pairs are sorted (by (-count, value), the order of
+// ans_reorder_fold.hpp:79-85); ranks are written back into the table and every input value is
+// remapped with one probe.
+// ------------------------------------------------------------------------------------------
+#define ANSX_RF_SLOTS 20480u  // >= 1.25 x 16384 values per block
+#define ANSX_RF_EMPTY 0xFFFFFFFFu
+
+__device__ __forceinline__ u32 rf_slot(u32 v) { return (u32)(((u64)(v * 2654435761u) * ANSX_RF_SLOTS) >> 32); }
+
+__global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict__ in, ansx_geo g,
+    u32* __restrict__ mapped, u32* __restrict__ mostfreq, ansx_blk* __restrict__ blk,
+    u32* __restrict__ gflags)
+{
+    extern __shared__ u8 smem_rh[];
+    __shared__ u32 sh_cnt;
+    __shared__ u32 sh_max;
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const u32 nb = geo_block_n(g, b);
+    const u32 T = fold_T(g.f);
+    u32* keys = (u32*)smem_rh;                                      // [SLOTS]
+    u32* cnt32 = (u32*)(smem_rh + 4 * (size_t)ANSX_RF_SLOTS);      // [SLOTS/2], two u16 counters each
+    u64* sel = (u64*)(smem_rh + 6 * (size_t)ANSX_RF_SLOTS);        // [T]
+    const u32* src = in + (u64)b * g.block_ints;
+    u32* dst = mapped + (u64)b * g.block_ints;
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) keys[i] = ANSX_RF_EMPTY;
+    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += 256) cnt32[i] = 0;
+    if (tid == 0) {
+        sh_cnt = 0;
+        sh_max = 0;
+    }
+    __syncthreads();
+    auto count_of = [&](u32 slot) -> u32 { return (cnt32[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu; };
+    // ---- insert: value -> count (counts <= 16384 fit 16 bits)
+    u32 lmax = 0, ldistinct = 0;
+    for (u32 i = tid; i < nb; i += 256) {
+        const u32 v = src[i];
+        lmax = v > lmax ? v : lmax;
+        u32 slot = rf_slot(v);
+        for (;;) {
+            const u32 old = atomicCAS(&keys[slot], ANSX_RF_EMPTY, v);
+            if (old == ANSX_RF_EMPTY) ldistinct++;
+            if (old == ANSX_RF_EMPTY || old == v) break;
+            slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+        }
+        atomicAdd(&cnt32[slot >> 1], 1u << (16 * (slot & 1)));
+    }
+    atomicMax(&sh_max, lmax);
+    atomicAdd(&sh_cnt, ldistinct);
+    __syncthreads();
+    const u32 sigma = sh_cnt;
+    const u32 vmax = sh_max;
+    if (sigma < T) {  // ans_reorder_fold.hpp:94-97: identity mapping, flag 0
+        for (u32 i = tid; i < nb; i += 256) dst[i] = src[i];
+        if (tid == 0) {
+            blk[b].flag = 0;
+            if (vmax >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
+        }
+        return;
+    }
+    if (tid == 0 && (u64)vmax + T >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
+    // Thresholds by radix selection over LDS histograms (no sorting, no bisection):
+    //   c*  = largest c with #values(count >= c) >= T        (2 levels of 7 bits, counts <= 16384)
+    //   v*  = K-th smallest value among those with count == c* (3 levels of 10 bits, values < 2^30)
+    // One table pass per level; lanes of wave 0 locate the bucket where the running total
+    // crosses the target.
+    u32* hist = (u32*)sel;  // 1024 bins, reuses the (not yet used) selection buffer (T*8 >= 4096 B
+                            // needs T >= 512; for T = 256 the buffer is sized for 512 entries)
+    // returns bucket index; *before = total of the buckets passed before it
+    auto find_bucket = [&](u32 nbins, u32 target, bool descending, u32* before) -> u32 {
+        __syncthreads();
+        if (tid < 64) {
+            const u32 per = (nbins + 63) / 64;
+            u32 loc = 0;
+            for (u32 i = 0; i < per; i++) {
+                u32 bin = tid * per + i;
+                if (descending) bin = nbins - 1 - bin;
+                loc += (tid * per + i < nbins) ? hist[bin] : 0u;
+            }
+            u32 incl = loc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 t = __shfl_up(incl, d);
+                if ((int)tid >= d) incl += t;
+            }
+            const u32 excl = incl - loc;
+            if (excl < target && incl >= target) {  // exactly one lane
+                u32 run = excl, found = 0, bef = excl;
+                for (u32 i = 0; i < per; i++) {
+                    u32 bin = tid * per + i;
+                    if (bin >= nbins) break;
+                    u32 hb = descending ? nbins - 1 - bin : bin;
+                    u32 c = hist[hb];
+                    if (run < target && run + c >= target) {
+                        found = hb;
+                        bef = run;
+                    }
+                    run += c;
+                }
+                sh_cnt = found;
+                sh_max = bef;
+            }
+        }
+        __syncthreads();
+        *before = sh_max;
+        return sh_cnt;
+    };
+    auto clear_hist = [&](u32 nbins) {
+        __syncthreads();
+        for (u32 i = tid; i < nbins; i += 256) hist[i] = 0;
+        __syncthreads();
+    };
+    u32 before;
+    // ---- c*: level 1 (count >> 7), level 2 (count & 127), scanned from the top
+    clear_hist(256);
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        const u32 c = count_of(i);
+        if (c) atomicAdd(&hist[c >> 7], 1u);
+    }
+    const u32 B1 = find_bucket(129, T, true, &before);
+    const u32 above1 = before;
+    clear_hist(128);
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        const u32 c = count_of(i);
+        if (c && (c >> 7) == B1) atomicAdd(&hist[c & 127], 1u);
+    }
+    const u32 b2 = find_bucket(128, T - above1, true, &before);
+    const u32 cstar = (B1 << 7) | b2;
+    const u32 G = above1 + before;   // values with count > c*: all selected
+    const u32 K = T - G;             // K smallest values with count == c*
+    __syncthreads();
+    const u32 ties = hist[b2];
+    u32 vstar = 0xFFFFFFFFu;  // values at the threshold count are selected iff value <= vstar
+    if (ties > K) {
+        clear_hist(1024);
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+            const u32 k = keys[i];
+            if (k != ANSX_RF_EMPTY && count_of(i) == cstar) atomicAdd(&hist[k >> 20], 1u);
+        }
+        const u32 V1 = find_bucket(1024, K, false, &before);
+        const u32 k1 = K - before;
+        clear_hist(1024);
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+            const u32 k = keys[i];
+            if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 20) == V1) atomicAdd(&hist[(k >> 10) & 1023], 1u);
+        }
+        const u32 V2 = find_bucket(1024, k1, false, &before);
+        const u32 k2 = k1 - before;
+        const u32 hi20 = (V1 << 10) | V2;
+        clear_hist(1024);
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+            const u32 k = keys[i];
+            if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 10) == hi20) atomicAdd(&hist[k & 1023], 1u);
+        }
+        const u32 V3 = find_bucket(1024, k2, false, &before);
+        vstar = (hi20 << 10) | V3;
+    }
+    __syncthreads();
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        const u32 k = keys[i];
+        if (k == ANSX_RF_EMPTY) continue;
+        const u32 c = count_of(i);
+        if (c > cstar || (c == cstar && k <= vstar)) {
+            const u32 slot = atomicAdd(&sh_cnt, 1u);
+            if (slot < T) sel[slot] = ((u64)(0xFFFFFFFFu - c) << 32) | (u64)k;  // (-count, value)
+        }
+    }
+    __syncthreads();
+    lds_bitonic_sort<u64>(sel, T, tid);
+    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += 256) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
+    __syncthreads();
+    u32* mf = mostfreq + (u64)b * T;
+    for (u32 r = tid; r < T; r += 256) {
+        const u32 v = (u32)sel[r];
+        mf[r] = v;  // ans_reorder_fold.hpp:104-105
+        u32 slot = rf_slot(v);
+        while (keys[slot] != v) slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+        // two ranks share a word: clear this half (0xFFFF -> r) with an atomic AND
+        atomicAnd(&cnt32[slot >> 1], ~(0xFFFFu << (16 * (slot & 1))) | (r << (16 * (slot & 1))));
+    }
+    __syncthreads();
+    for (u32 i = tid; i < nb; i += 256) {
+        const u32 v = src[i];
+        u32 slot = rf_slot(v);
+        while (keys[slot] != v) slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+        const u32 r = count_of(slot);
+        dst[i] = (r != 0xFFFFu) ? r : v + T;  // :99-103
+    }
+    if (tid == 0) blk[b].flag = 1;
+}

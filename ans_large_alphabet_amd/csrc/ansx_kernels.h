@@ -335,7 +335,9 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     const u32 ns = B.max_sym + 1;
     const u32* h = hist + (u64)b * NSP;
     const double nd = (double)(int)B.n;
-    const double md = (double)(int)(1u << sh);
+    // q = S / M with M = 2^sh: the division by a power of two is exact, so it is a multiply
+    // (sh == 31 would make (int)M negative in util.hpp:289; such frames never reach this point)
+    const double inv_md = ansx_bits_to_f64((u64)(1023 - sh) << 52);
     double acc = 0.0;
     uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4), sv = *(const uint4*)(S);
     for (u32 i0 = 0; i0 < ns; i0 += 8) {
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
             const double p = valid ? (double)h8[u] / nd : 0.0;
-            const double q = valid ? (double)s8[u] / md : 1.0;
+            const double q = valid ? (double)s8[u] * inv_md : 1.0;
             tm[u] = p * ansx_log2_portable(q);
         }
 #pragma unroll
@@ -725,7 +727,8 @@ template <> struct enc_tab<true> {
     }
 };
 
-#define ANSX_ENC_U 8  // symbols per lane kept in flight by the software pipeline
+#define ANSX_ENC_U 8    // table entries per lane fetched ahead
+#define ANSX_ENC_XB 32  // inputs per lane fetched ahead (one super-batch)
 
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
@@ -788,63 +791,61 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         }
     };
     u32 gi = G;  // groups [0, gi) remain
-    // leading remainder so that the pipelined part covers a multiple of U groups
-    for (u32 t = G % ANSX_ENC_U; t > 0; t--) {
+    // leading remainder so that the pipelined part covers a multiple of XB groups
+    for (u32 t = G % ANSX_ENC_XB; t > 0; t--) {
         const u32 gidx = --gi;
         u32 x = src[4 * gidx + 3 - ql];
         enc_update(L, x, tab.get(f, x), true, ql, logM, out);
         record(gidx);
     }
-    // software pipeline over batches of U groups: while batch t is encoded, the table entries
-    // of batch t+1 and the inputs of batch t+2 are in flight, so the per-symbol dependency
-    // chain (renorm test -> divide -> state) never waits on memory.
+    // Software pipeline.  Inputs are fetched XB groups (one "super-batch") ahead into registers;
+    // table entries (LDS) U groups ahead.  On CDNA4 stores share the in-order vmcnt with loads
+    // and the emitted-byte stores are predicated, so consuming a prefetched input costs a full
+    // drain of the store queue: doing that once per XB = 32 steps instead of once per U = 8 is
+    // what the deep input prefetch buys.  The per-symbol dependency chain
+    // (renorm test -> divide -> state) never waits on memory.
     if (gi) {
-        // restart points fall on batch boundaries when the interval is a multiple of U groups
+        // restart points fall on sub-batch boundaries when the interval is a multiple of U groups
         const bool ck_per_batch = (cg % ANSX_ENC_U) == 0;
         const u32* base = src + 3 - ql;
-        u32 x1[ANSX_ENC_U], x2[ANSX_ENC_U];
-        enc_ent e1[ANSX_ENC_U];
+        u32 xa[ANSX_ENC_XB], xb[ANSX_ENC_XB];
 #pragma unroll
-        for (int j = 0; j < ANSX_ENC_U; j++) x1[j] = base[4 * (gi - 1 - j)];
-#pragma unroll
-        for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, x1[j]);
-        if (gi >= 2 * ANSX_ENC_U) {
-#pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (gi - ANSX_ENC_U - 1 - j)];
-        } else {
-#pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = 0;
-        }
+        for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = base[4 * (gi - 1 - j)];
         while (gi) {
-            u32 x0[ANSX_ENC_U];
-            enc_ent e0[ANSX_ENC_U];
+            const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
+            if (top >= 2 * ANSX_ENC_XB) {
 #pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) {
-                x0[j] = x1[j];
-                e0[j] = e1[j];
-                x1[j] = x2[j];
+                for (int j = 0; j < ANSX_ENC_XB; j++) xb[j] = base[4 * (top - ANSX_ENC_XB - 1 - j)];
             }
-            const u32 top = gi;  // this batch encodes groups top-1 ... top-U
-            if (top >= 2 * ANSX_ENC_U) {
+            enc_ent e1[ANSX_ENC_U];
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, x1[j]);
-            }
-            if (top >= 3 * ANSX_ENC_U) {
+            for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, xa[j]);
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) x2[j] = base[4 * (top - 2 * ANSX_ENC_U - 1 - j)];
-            }
-            if (ck_per_batch) {
+            for (int sb = 0; sb < ANSX_ENC_XB / ANSX_ENC_U; sb++) {
+                enc_ent e0[ANSX_ENC_U];
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) enc_update(L, x0[j], e0[j], true, ql, logM, out);
-                record(top - ANSX_ENC_U);
-            } else {
+                for (int j = 0; j < ANSX_ENC_U; j++) e0[j] = e1[j];
+                if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) {
-                    enc_update(L, x0[j], e0[j], true, ql, logM, out);
-                    record(top - 1 - j);
+                    for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, xa[(sb + 1) * ANSX_ENC_U + j]);
+                }
+                const u32 sbtop = top - sb * ANSX_ENC_U;  // groups sbtop-1 ... sbtop-U
+                if (ck_per_batch) {
+#pragma unroll
+                    for (int j = 0; j < ANSX_ENC_U; j++)
+                        enc_update(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, out);
+                    record(sbtop - ANSX_ENC_U);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ANSX_ENC_U; j++) {
+                        enc_update(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, out);
+                        record(sbtop - 1 - j);
+                    }
                 }
             }
-            gi = top - ANSX_ENC_U;
+            gi = top - ANSX_ENC_XB;
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = xb[j];
         }
     }
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)

@@ -42,7 +42,7 @@ struct __attribute__((aligned(16))) ansx_enc_entry {
 };
 
 enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3 };
-enum { ANSX_ATTEMPTS = 4 };  // frame sizes tried per batch
+enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 
 // ------------------------------------------------------------------------------------------
 // K1: folded-symbol histogram.  One workgroup per chunk of a block; LDS bins; coalesced 16 B

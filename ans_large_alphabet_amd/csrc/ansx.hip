@@ -344,6 +344,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t LDS_LIMIT = 150 * 1024;
     // stage the block stream in LDS when (tables + stream) still leaves >= 3 workgroups per CU
     size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
+    if (getenv("ANSX_NO_STREAM_LDS")) want_stream = (size_t)1 << 30;  // experiment switch
     if (tables <= LDS_LIMIT) {
         size_t lds = tables;
         u32 stream_cap = 0;

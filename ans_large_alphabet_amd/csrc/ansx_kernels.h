@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 // ------------------------------------------------------------------------------------------
 #define ANSX_VMAX 2048u
 
+// Single-wave workgroups: LDS operations of one wave execute in order, so a "barrier" only has
+// to stop the compiler from reordering and wait for the LDS queue; __syncthreads() would also
+// drain every outstanding global store (vmcnt(0)) at each call.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk)
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     for (u32 s = lane; s < ns; s += 64) hrow[s] = h[s];
     for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
     if (lane == 0) sh_nbig = 0;
-    __syncthreads();
+    wave_lds_sync();
     // pass 1: bin the frequencies
     u32 sigma = 0;
     u64 total = 0;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         sigma += __shfl_xor(sigma, o);
         total += __shfl_xor(total, o);
     }
-    __syncthreads();
+    wave_lds_sync();
     // pass 2: exclusive scan of the bins -> first output position of every frequency value
     u32 nsmall;
     {
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             run += t;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // pass 3: stable placement, 64 symbols at a time in index order
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             todo &= ~m;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // big symbols: rank among themselves by (freq, sym)
     const u32 nbig = sh_nbig < nbig_cap ? sh_nbig : nbig_cap;
     for (u32 i = lane; i < nbig; i += 64) {
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     const double nd = (double)total;
     double acc = 0.0;
     for (u32 base = 0; base < ns; base += 512) {
-        __syncthreads();
+        wave_lds_sync();
         for (u32 u = lane; u < 512; u += 64) {
             u32 i = base + u;
             u32 fr = i < ns ? hrow[i] : 0u;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             double q = fr ? p : 1.0;
             terms[u] = p * ansx_log2_portable(q);
         }
-        __syncthreads();
+        wave_lds_sync();
         if (lane == 0) {
             u32 lim = ns - base < 512 ? ns - base : 512;
             u32 u = 0;
@@ -292,7 +297,10 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     double fsd = (double)B.n;
     const u32* F = sortF + (u64)b * NSP;
     const u16* Sy = sortSym + (u64)b * NSP;
-    u16* S = attS + ((u64)b * ANSX_ATTEMPTS + t) * NSP;
+    // candidate frequencies, layout [block][symbol][attempt]: the ANSX_ATTEMPTS lanes of a block
+    // write / read 16 contiguous bytes per symbol (scattered 2-byte stores into per-attempt rows
+    // cost 12x write amplification, measured with WRITE_SIZE)
+    u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + t;
     u32 maxS = 0;
     const u32 sigma = B.sigma;
     bool stop = false;
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
                 v = 0.5 + v;
                 u32 sc = (u32)v;
                 if (sc == 0) sc = 1;
-                S[sy8[u]] = (u16)(sc > 65535u ? 65535u : sc);
+                S[sy8[u] * ANSX_ATTEMPTS] = (u16)(sc > 65535u ? 65535u : sc);
                 maxS = sc > maxS ? sc : maxS;
                 Md = Md - (double)sc;
                 fsd = fsd - frd;
@@ -339,15 +347,15 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     // (sh == 31 would make (int)M negative in util.hpp:289; such frames never reach this point)
     const double inv_md = ansx_bits_to_f64((u64)(1023 - sh) << 52);
     double acc = 0.0;
-    uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4), sv = *(const uint4*)(S);
+    uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4);
     for (u32 i0 = 0; i0 < ns; i0 += 8) {
         const u32 h8[8] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w };
-        const u32 s8[8] = { sv.x & 0xFFFFu, sv.x >> 16, sv.y & 0xFFFFu, sv.y >> 16,
-            sv.z & 0xFFFFu, sv.z >> 16, sv.w & 0xFFFFu, sv.w >> 16 };
+        u32 s8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s8[u] = S[(u64)(i0 + u) * ANSX_ATTEMPTS];  // rows are NSP >= ns+8 long
         if (i0 + 8 < ns) {
             ha = *(const uint4*)(h + i0 + 8);
             hb = *(const uint4*)(h + i0 + 12);
-            sv = *(const uint4*)(S + i0 + 8);
         }
         double tm[8];
 #pragma unroll
@@ -401,9 +409,9 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     if (chosen == -2) {
         // still undecided after this batch: remember the last rejected success
         if (prev >= (int)(batch * ANSX_ATTEMPTS)) {
-            const u16* S = attS + ((u64)b * ANSX_ATTEMPTS + (prev - batch * ANSX_ATTEMPTS)) * NSP;
+            const u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + (prev - batch * ANSX_ATTEMPTS);
             u16* P = prevS + (u64)b * NSP;
-            for (u32 s = lane; s < ns; s += 64) P[s] = S[s];
+            for (u32 s = lane; s < ns; s += 64) P[s] = S[(u64)s * ANSX_ATTEMPTS];
         }
         if (lane == 0) {
             B->prev = prev;
@@ -425,9 +433,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         }
         return;
     }
-    const u16* S = (chosen >= (int)(batch * ANSX_ATTEMPTS))
-        ? attS + ((u64)b * ANSX_ATTEMPTS + (chosen - batch * ANSX_ATTEMPTS)) * NSP
-        : prevS + (u64)b * NSP;
+    const bool from_batch = chosen >= (int)(batch * ANSX_ATTEMPTS);
+    const u16* S = from_batch ? attS + (u64)b * ANSX_ATTEMPTS * NSP + (chosen - batch * ANSX_ATTEMPTS)
+                              : prevS + (u64)b * NSP;
+    const u32 sstride = from_batch ? ANSX_ATTEMPTS : 1u;
     // exclusive scan of the chosen frequencies -> encoder table (ans_fold.hpp:82-91):
     // lane = symbol, 64 symbols per pass (coalesced), wave prefix sum, carry between passes
     ansx_enc_entry* tab = table + (u64)b * NSP;
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
         const u32 hv = s < ns ? h[s] : 0u;
-        const u32 sv = s < ns ? (u32)S[s] : 0u;
+        const u32 sv = s < ns ? (u32)S[(u64)s * sstride] : 0u;
         const u32 fr = hv ? sv : 0u;
         u32 incl = fr;
 #pragma unroll

@@ -29,6 +29,16 @@ def A():
 
 @pytest.fixture(scope="module")
 def ctx(A, oracle_built):
+    # Same order as bench.py: torch (which bundles its own HIP runtime) initialises the device
+    # first, libansx then shares that runtime.  On a fresh box the first `import torch` can take
+    # minutes while the image pages in; doing it here keeps that out of the individual tests.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     return A.Context(0)
 
 

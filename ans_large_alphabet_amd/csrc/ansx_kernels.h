@@ -1180,6 +1180,9 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
 // ---- K8: one workgroup per block.  Loads the parsed table (coalesced), builds the
 // slot -> symbol table, stages the block's stream in LDS when it fits, then one quad of lanes
 // per segment decodes forward from its restart point.
+// (Measured alternatives on MI355X, 256 Mi ints: no staging 1.56 ms; whole-stream staging 1.38 ms;
+// a 512-byte per-quad ring refilled through registers 1.62 ms -- more occupancy, but every refill
+// waits on the in-order vmcnt behind the outstanding output stores.)
 template <bool LDS_TAB, bool RFOLD>
 __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
@@ -1187,7 +1190,7 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     u32 max_ns, u32 stream_cap, u16* __restrict__ g_s2s, u32* __restrict__ g_cum,
     const uint4* __restrict__ binfo, u32* __restrict__ gflags)
 {
-    extern __shared__ u8 smem[];
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
     __shared__ u32 sh_bad;
     const u32 tid = threadIdx.x, nt = blockDim.x;
     const u32 b = blockIdx.x;

@@ -87,6 +87,32 @@ def cpu_baseline(sample, kind, f):
     }
 
 
+def pmc_traffic(kernel, args, n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate
+    passes, gfx950 correction calibrated on k_fold_hist).  Counters cannot be read from inside
+    this process, so the figure is only reported when the workload is the profiled one."""
+    try:
+        import glob
+
+        best = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json"))):
+            with open(path) as fh:
+                best = json.load(fh)
+        if best is None:
+            return None
+        want = "ANS%s-%d, %d ints, %s, block %d, ckpt %d" % (args.codec, args.fidelity, n, args.dist,
+                                                              args.block or 16384, args.ckpt or 1024)
+        if best.get("workload") != want:
+            return None
+        for name, v in best["kernels"].items():
+            if name.split("<")[0] == kernel:
+                return v["hbm_bytes"]
+    except Exception:
+        return None
+    return None
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -214,7 +240,7 @@ def main():
                "k_fold_hist": 4.0 * n, "k_compact": 2 * c_bytes * n, "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args, n),
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms}
 
     cpu = None

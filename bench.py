@@ -53,7 +53,7 @@ def gen_uniform(torch, n, lo, hi, seed, device):
     return torch.randint(lo, hi + 1, (n,), generator=g, device=device, dtype=torch.int32)
 
 
-def cpu_baseline(sample, kind, f):
+def cpu_baseline(sample, kind, f, block_ints=16384):
     """Reference CPU path, one thread, whole-list encode()+decode() as table_efficiency.cpp
     times it (min over runs).  Uses oracle/ strictly as the measured CPU comparator."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -77,7 +77,27 @@ def cpu_baseline(sample, kind, f):
         back = ol.ref_decode(kind, f, stream, n) if use_ref else ol.oracle_decode(kind, f, stream, n)
         t_dec = min(t_dec, time.perf_counter() - t0)
     ok = bool(np.array_equal(back, sample))
+    # like-for-like row: the same data encoded/decoded block by block (one reference encode()
+    # per block_ints ints, exactly the units the GPU processes), on a slice of the sample
+    blk_n = min(n, 8 * (1 << 20))
+    tb_enc = tb_dec = 0.0
+    streams = []
+    for a in range(0, blk_n, block_ints):
+        part = np.ascontiguousarray(sample[a:a + block_ints])
+        t0 = time.perf_counter()
+        s_ = ol.ref_encode(kind, f, part) if use_ref else ol.oracle_encode(kind, f, part)[0]
+        tb_enc += time.perf_counter() - t0
+        streams.append((s_, part.size))
+    for s_, m in streams:
+        t0 = time.perf_counter()
+        _ = ol.ref_decode(kind, f, s_, m) if use_ref else ol.oracle_decode(kind, f, s_, m)
+        tb_dec += time.perf_counter() - t0
+    blocked = {"block_ints": block_ints, "ints": blk_n, "value": blk_n / (tb_enc + tb_dec) / 1e6,
+               "enc_mints": blk_n / tb_enc / 1e6, "dec_mints": blk_n / tb_dec / 1e6,
+               "bits_per_int": 8.0 * sum(s_.size for s_, _ in streams) / blk_n,
+               "note": "includes ~10 us of ctypes/numpy call overhead per block"}
     return {
+        "blocked": blocked,
         "value": n / (t_enc + t_dec) / 1e6, "unit": "Mints/s", "cores": 1,
         "kind": "reference" if use_ref else "port",
         "sample": "first %d ints of the workload, one whole-list encode()+decode(), min of %d runs" % (n, runs),
@@ -247,7 +267,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         m = min(n, args.cpu_sample)
         sample = d_in[:m].cpu().numpy().view("uint32")
-        cpu = cpu_baseline(sample, kind, args.fidelity)
+        cpu = cpu_baseline(sample, kind, args.fidelity, args.block or A.DEFAULT_BLOCK_INTS)
 
     if rank == 0:
         line = {

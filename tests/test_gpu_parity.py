@@ -305,3 +305,35 @@ def test_rank_shards_merge_into_one_decodable_container(A, ctx):
     whole = codec.encode(data)
     assert np.array_equal(merged, whole)
     assert np.array_equal(codec.decode(merged, n), data)
+
+
+def test_corrupted_payload_never_faults(A, ctx):
+    """Random byte corruption anywhere in the container: the decoder must either report
+    ANSX_ERR_FORMAT or return (wrong) data — never fault — and the context stays usable."""
+    rng = np.random.default_rng(77)
+    data = ol.gen_inputs("zipf20s1.2", 60000, seed=4)
+    for kind, f in ((ol.FOLD, 1), (ol.RFOLD, 1), (ol.FOLD, 3)):
+        codec = codec_for(A, ctx, kind, f, block_ints=4096, ckpt_interval=512)
+        cont = codec.encode(data).copy()
+        for trial in range(40):
+            bad = cont.copy()
+            region = trial % 4
+            if region == 0:      # header
+                pos = rng.integers(8, 64, size=2)
+            elif region == 1:    # index + restart points
+                pos = rng.integers(64, int(A.parse_container(cont)["header"].payload_offset), size=4)
+            else:                # payload (preludes, exception bytes, renorm words, final states)
+                pos = rng.integers(int(A.parse_container(cont)["header"].payload_offset), cont.size, size=8)
+            bad[pos] ^= rng.integers(1, 256, size=len(pos)).astype(np.uint8)
+            try:
+                out = codec.decode(bad, data.size)
+                assert out.size == data.size
+            except A.AnsxError as e:
+                assert e.status in (1, 3), e.status
+        assert np.array_equal(codec.decode(cont, data.size), data)
+    # truncated containers
+    codec = codec_for(A, ctx, ol.FOLD, 1, block_ints=4096, ckpt_interval=512)
+    cont = codec.encode(data)
+    for cut in (0, 10, 63, 64, 200, cont.size // 2, cont.size - 1):
+        with pytest.raises(A.AnsxError):
+            codec.decode(cont[:cut].copy() if cut else np.zeros(1, dtype=np.uint8), data.size)

@@ -174,14 +174,34 @@ int flags_to_status(u32 fl)
 }
 
 // --------------------------------------------------------------------------------- rfold
-// ans_reorder_fold.hpp:70-106 on the device.  One workgroup sorts one block in LDS, so the
-// block must fit: block_ints <= 16384 (whole-list ANSrfold of longer inputs needs a global
-// sort and is not built yet — callers get ANSX_ERR_ARG).
+// ans_reorder_fold.hpp:70-106 on the device: LDS hash table per block for blocks <= 16384 ints,
+// HBM hash table for longer blocks (incl. whole-list single-stream mode).
 int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u32* mostfreq,
     ansx_blk* blk, u32* gflags, hipStream_t s)
 {
-    if (g.block_ints > 16384u) return ANSX_ERR_ARG;
     const u32 T = fold_T(g.f);
+    if (g.block_ints > 16384u) {
+        // large blocks (incl. whole-list single-stream mode): hash table in HBM
+        u32 slots = 2;
+        while ((u64)slots < 2ull * g.block_ints && slots < (1u << 31)) slots <<= 1;
+        int rc;
+        if ((rc = ensure(c, c->rf_tmp, (size_t)g.nblocks * slots * 8 + (size_t)g.nblocks * 16))) return rc;
+        u32* keys = (u32*)c->rf_tmp.p;
+        u32* counts = keys + (size_t)g.nblocks * slots;
+        u32* bstat = counts + (size_t)g.nblocks * slots;
+        HIPCHK(c, hipMemsetAsync(keys, 0xFF, (size_t)g.nblocks * slots * 4, s));
+        HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)g.nblocks * slots * 4 + (size_t)g.nblocks * 16, s));
+        const size_t grid = (g.n + 255) / 256;
+        LAUNCH(c, "k_rfg_insert", k_rfg_insert, grid, 256, 0, s, d_in, g, slots, keys, counts, bstat);
+        if ((size_t)T * 8 > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_rfg_select,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)T * 8)));
+        LAUNCH(c, "k_rfg_select", k_rfg_select, g.nblocks, 256, (size_t)T * 8, s, g, slots, (const u32*)keys,
+            counts, (const u32*)bstat, mostfreq, blk, gflags);
+        LAUNCH(c, "k_rfg_map", k_rfg_map, grid, 256, 0, s, d_in, g, slots, (const u32*)keys, (const u32*)counts,
+            (const ansx_blk*)blk, mapped);
+        return ANSX_OK;
+    }
     if (T <= 4096) {  // hash-table form
         size_t lds = 6 * (size_t)ANSX_RF_SLOTS + 8 * (size_t)(T < 512 ? 512 : T);  // also holds a 1024-bin histogram
         HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash,

@@ -368,3 +368,176 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     }
     if (tid == 0) blk[b].flag = 1;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// K9 (large blocks, any block_ints < 2^31, e.g. whole-list single-stream mode): the same
+// selection with the hash table in HBM.  Table per block: `slots` (power of two >= 2 x block
+// size) keys + counts.  k_rfg_insert counts values with global atomics, k_rfg_select (one
+// workgroup per block) finds c*, v* by radix selection over the table (8-bit levels, LDS
+// histograms), sorts the T selected pairs and writes their ranks over the counts, k_rfg_map
+// rewrites every value with one probe.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 rfg_hash(u32 v, u32 mask) { return (v * 2654435761u) & mask; }
+
+__global__ __launch_bounds__(256) void k_rfg_insert(const u32* __restrict__ in, ansx_geo g, u32 slots,
+    u32* __restrict__ keys, u32* __restrict__ counts, u32* __restrict__ bstat /* [nb][4]: sigma, vmax */)
+{
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= g.n) return;
+    const u32 b = (u32)(gid / g.block_ints);
+    const u32 v = in[gid];
+    u32* K = keys + (u64)b * slots;
+    u32* C = counts + (u64)b * slots;
+    const u32 mask = slots - 1;
+    u32 slot = rfg_hash(v, mask);
+    for (;;) {
+        const u32 old = atomicCAS(&K[slot], ANSX_RF_EMPTY, v);
+        if (old == ANSX_RF_EMPTY) atomicAdd(&bstat[4 * b + 0], 1u);
+        if (old == ANSX_RF_EMPTY || old == v) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicAdd(&C[slot], 1u);
+    if (__hip_atomic_load(&bstat[4 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v)
+        atomicMax(&bstat[4 * b + 1], v);
+}
+
+__global__ __launch_bounds__(256) void k_rfg_select(ansx_geo g, u32 slots, const u32* __restrict__ keys,
+    u32* __restrict__ counts, const u32* __restrict__ bstat, u32* __restrict__ mostfreq,
+    ansx_blk* __restrict__ blk, u32* __restrict__ gflags)
+{
+    extern __shared__ u64 sel_g[];  // [T]
+    __shared__ u32 hist[256];
+    __shared__ u32 sh_a, sh_b;
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const u32 T = fold_T(g.f);
+    const u32* K = keys + (u64)b * slots;
+    u32* C = counts + (u64)b * slots;
+    const u32 sigma = bstat[4 * b + 0], vmax = bstat[4 * b + 1];
+    if (sigma < T) {  // ans_reorder_fold.hpp:94-97
+        if (tid == 0) {
+            blk[b].flag = 0;
+            if (vmax >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
+        }
+        return;
+    }
+    if (tid == 0 && (u64)vmax + T >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
+    // one radix level: histogram of digit(slot) over the slots passing `pred`, then the bucket
+    // where the running total (from the top if descending) reaches `target`
+    auto level = [&](auto pred, auto digit, u32 target, bool descending, u32* before) -> u32 {
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < slots; i += 256) {
+            const u32 k = K[i];
+            if (k == ANSX_RF_EMPTY) continue;
+            const u32 c = C[i];
+            if (pred(k, c)) atomicAdd(&hist[digit(k, c)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0, found = 0, bef = 0;
+            bool done = false;
+            for (u32 j = 0; j < 256 && !done; j++) {
+                const u32 d = descending ? 255 - j : j;
+                const u32 h = hist[d];
+                if (run + h >= target) {
+                    found = d;
+                    bef = run;
+                    done = true;
+                }
+                run += h;
+            }
+            sh_a = found;
+            sh_b = bef;
+        }
+        __syncthreads();
+        *before = sh_b;
+        return sh_a;
+    };
+    // ---- c* = largest c with #(count >= c) >= T: four 8-bit levels from the top
+    u32 before, prefix = 0, need = T;
+    for (int lv = 3; lv >= 0; lv--) {
+        const u32 sh = 8 * lv;
+        const u32 pfx = prefix;
+        const u32 d = level([&](u32, u32 c) { return lv == 3 || (c >> (sh + 8)) == (pfx >> (sh + 8)); },
+            [&](u32, u32 c) { return (c >> sh) & 255u; }, need, true, &before);
+        prefix |= d << sh;
+        need -= before;
+    }
+    const u32 cstar = prefix;
+    const u32 K_take = need;  // values with count == c* still to take (the smallest ones)
+    // number of ties
+    __syncthreads();
+    if (tid == 0) sh_a = 0;
+    __syncthreads();
+    {
+        u32 l = 0;
+        for (u32 i = tid; i < slots; i += 256)
+            if (K[i] != ANSX_RF_EMPTY && C[i] == cstar) l++;
+        atomicAdd(&sh_a, l);
+    }
+    __syncthreads();
+    const u32 ties = sh_a;
+    u32 vstar = 0xFFFFFFFFu;
+    if (ties > K_take) {  // K_take-th smallest value among the ties
+        u32 vp = 0, vneed = K_take;
+        for (int lv = 3; lv >= 0; lv--) {
+            const u32 sh = 8 * lv;
+            const u32 pfx = vp;
+            const u32 d = level([&](u32 k, u32 c) { return c == cstar && (lv == 3 || (k >> (sh + 8)) == (pfx >> (sh + 8))); },
+                [&](u32 k, u32) { return (k >> sh) & 255u; }, vneed, false, &before);
+            vp |= d << sh;
+            vneed -= before;
+        }
+        vstar = vp;
+    }
+    __syncthreads();
+    if (tid == 0) sh_a = 0;
+    __syncthreads();
+    for (u32 i = tid; i < slots; i += 256) {
+        const u32 k = K[i];
+        if (k == ANSX_RF_EMPTY) continue;
+        const u32 c = C[i];
+        if (c > cstar || (c == cstar && k <= vstar)) {
+            const u32 s = atomicAdd(&sh_a, 1u);
+            if (s < T) sel_g[s] = ((u64)(0xFFFFFFFFu - c) << 32) | (u64)k;
+        }
+    }
+    __syncthreads();
+    lds_bitonic_sort<u64>(sel_g, T, tid);
+    for (u32 i = tid; i < slots; i += 256) C[i] = 0xFFFFFFFFu;  // rank, 0xFFFFFFFF = not selected
+    __threadfence_block();
+    __syncthreads();
+    u32* mf = mostfreq + (u64)b * T;
+    const u32 mask = slots - 1;
+    for (u32 r = tid; r < T; r += 256) {
+        const u32 v = (u32)sel_g[r];
+        mf[r] = v;
+        u32 slot = rfg_hash(v, mask);
+        while (K[slot] != v) slot = (slot + 1) & mask;
+        C[slot] = r;
+    }
+    if (tid == 0) blk[b].flag = 1;
+}
+
+__global__ __launch_bounds__(256) void k_rfg_map(const u32* __restrict__ in, ansx_geo g, u32 slots,
+    const u32* __restrict__ keys, const u32* __restrict__ counts, const ansx_blk* __restrict__ blk,
+    u32* __restrict__ mapped)
+{
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= g.n) return;
+    const u32 b = (u32)(gid / g.block_ints);
+    const u32 v = in[gid];
+    if (!blk[b].flag) {
+        mapped[gid] = v;
+        return;
+    }
+    const u32* K = keys + (u64)b * slots;
+    const u32 mask = slots - 1;
+    u32 slot = rfg_hash(v, mask);
+    while (K[slot] != v) slot = (slot + 1) & mask;
+    const u32 r = counts[(u64)b * slots + slot];
+    mapped[gid] = (r != 0xFFFFFFFFu) ? r : v + fold_T(g.f);
+}

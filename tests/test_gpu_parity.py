@@ -155,8 +155,6 @@ def test_golden_fixtures_large(A, ctx):
     with open(os.path.join(GOLD, "large.json")) as fh:
         gold = json.load(fh)
     for e in gold:
-        if e["kind"] == "rfold" and e["n"] > 16384:
-            continue  # whole-list ANSrfold beyond one LDS block is not built yet
         data = ol.gen_inputs(e["family"], e["n"], e["seed"])
         if e["kind"] == "rfold":
             data = data % np.uint32(1 << 21)
@@ -337,3 +335,20 @@ def test_corrupted_payload_never_faults(A, ctx):
     for cut in (0, 10, 63, 64, 200, cont.size // 2, cont.size - 1):
         with pytest.raises(A.AnsxError):
             codec.decode(cont[:cut].copy() if cut else np.zeros(1, dtype=np.uint8), data.size)
+
+
+@pytest.mark.parametrize("f", [1, 3])
+def test_rfold_large_blocks_and_whole_list(A, ctx, f):
+    """Blocks longer than one LDS hash table (HBM hash-table path), incl. single-stream mode."""
+    n = 200003
+    for fam in ("zipf20s1.2", "uniform20", "geom0.01"):
+        data = ol.gen_inputs(fam, n, seed=31 * f)
+        codec = codec_for(A, ctx, ol.RFOLD, f, block_ints=65536, ckpt_interval=4096)
+        cont = codec.encode(data)
+        check_container(A, cont, data, ol.RFOLD, f, 65536, 4096)
+        assert np.array_equal(codec.decode(cont, n), data)
+        codec = codec_for(A, ctx, ol.RFOLD, f, block_ints=A.SINGLE_STREAM)
+        s = codec.encode(data)
+        exp, info, _, _ = ol.oracle_encode(ol.RFOLD, f, data)
+        assert np.array_equal(s, exp), (f, fam)
+        assert np.array_equal(codec.decode(s, n), data)

@@ -651,8 +651,9 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
 // exactly through the reciprocal stored in the table plus a +-1 correction.
 // ------------------------------------------------------------------------------------------
 struct enc_lane {
-    u64 st;
-    u32 p;  // byte cursor relative to the block's stream start (uniform within the quad)
+    u64 st;     // integer form (global-table variant, restart points, flush)
+    double sd;  // f64 form (LDS-table variant): exact, state < 2^36 * M <= 2^52
+    u32 p;      // byte cursor relative to the block's stream start (uniform within the quad)
 };
 
 // one symbol of one state.  x: value (its exception-byte count k in e.k); e: its table entry,
@@ -703,10 +704,65 @@ __device__ __forceinline__ void enc_update(enc_lane& L, u32 x, const enc_ent e, 
     L.p += total;
 }
 
+// The same step with the state carried as a double (LDS-table variant, M <= 2^16).  Every
+// quantity is an integer below 2^53, so all operations are exact:
+//   renorm   state >= 2^36*freq  <=>  sd >= thr;   hi = trunc(sd * 2^-32), w = sd - hi*2^32
+//   divide   q ~ trunc(s * rcp) (within +-1), r = fma(-q, F, s) exact, +-1 correction
+//   update   sd' = fma(q, M, r + base)  < 2^52 + 2^17
+// No int<->f64 conversion, 64-bit shift or 32-bit integer multiply sits on the dependency chain
+// (those slow-rate operations cost ~0.37 ms of the 1.40 ms integer form, measured by ablation).
+struct enc_ent_d {
+    double Fd, based, rcp, thr;
+    u32 k;
+};
+
+__device__ __forceinline__ void enc_update_d(enc_lane& L, u32 x, const enc_ent_d e, bool active, u32 ql,
+    double Md, u8* __restrict__ out)
+{
+    const u32 k = e.k;
+    const u32 eb = x & ((1u << (8 * k)) - 1u);
+    const double sd = L.sd;
+    const bool rn = active && (sd >= e.thr);
+    const double hi = __builtin_trunc(sd * (1.0 / 4294967296.0));
+    const double wd = __builtin_fma(-hi, 4294967296.0, sd);
+    const u32 w = (u32)wd;
+    const double s0 = rn ? hi : sd;
+    double qd = __builtin_trunc(s0 * e.rcp);
+    double rd = __builtin_fma(-qd, e.Fd, s0);
+    const double adj = (rd < 0.0) ? -1.0 : ((rd >= e.Fd) ? 1.0 : 0.0);
+    qd = qd + adj;
+    rd = __builtin_fma(-adj, e.Fd, rd);
+    const double nsd = __builtin_fma(qd, Md, rd + e.based);
+    if (active) L.sd = nsd;
+    const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
+    u32 total;
+    const u32 incl = quad_incl_scan(c, ql, &total);
+    u8* a = out + (L.p + (incl - c));
+#ifndef ANSX_ABL_NOSTORE
+    if (active) {
+        if (k == 1) a[0] = (u8)eb;
+        if (k >= 2) st_u16_unaligned(a, (u16)eb);
+        if (k == 3) a[2] = (u8)(eb >> 16);
+        if (rn) st_u32_unaligned(a + k, w);
+    }
+#else
+    asm volatile("" ::"v"(a), "v"(eb), "v"(w));
+#endif
+    L.p += total;
+}
+
+__device__ __forceinline__ u64 f64_to_u64_exact(double d)  // d is an integer in [0, 2^53)
+{
+    const double hi = __builtin_trunc(d * (1.0 / 4294967296.0));
+    const double lo = __builtin_fma(-hi, 4294967296.0, d);
+    return ((u64)(u32)hi << 32) | (u64)(u32)lo;
+}
+
 // table access: LDS-resident compact entries (base << 16 | freq) or the 16-byte global entries
 template <bool LDS_TABLE> struct enc_tab;
 template <> struct enc_tab<false> {
     const ansx_enc_entry* t;
+    typedef enc_ent ent;
     __device__ __forceinline__ enc_ent get(u32 f, u32 x) const
     {
         enc_ent r;
@@ -717,23 +773,38 @@ template <> struct enc_tab<false> {
         r.rcp = e.rcp;
         return r;
     }
+    __device__ __forceinline__ void step(enc_lane& L, u32 x, const enc_ent& e, bool active, u32 ql, u32 logM,
+        double, u8* __restrict__ out) const
+    {
+        enc_update(L, x, e, active, ql, logM, out);
+    }
+    __device__ __forceinline__ void init(enc_lane& L, u64 Lb) const { L.st = Lb; }
+    __device__ __forceinline__ u64 state(const enc_lane& L) const { return L.st; }
 };
 template <> struct enc_tab<true> {
     const u32* t;  // LDS
-    __device__ __forceinline__ enc_ent get(u32 f, u32 x) const
+    typedef enc_ent_d ent;
+    __device__ __forceinline__ enc_ent_d get(u32 f, u32 x) const
     {
-        enc_ent r;
+        enc_ent_d r;
         r.k = fold_nbytes(f, x);
         const u32 e = t[fold_sym(f, x, r.k)];
-        r.freq = e & 0xFFFFu;
-        r.base = e >> 16;
+        r.Fd = (double)(e & 0xFFFFu);
+        r.based = (double)(e >> 16);
         // 1/freq: hardware seed + one Newton step (relative error ~2^-50, far below the 2^-37
-        // the +-1 correction in enc_update needs)
-        const double fd = (double)r.freq;
-        const double r0 = __builtin_amdgcn_rcp(fd);
-        r.rcp = __builtin_fma(__builtin_fma(-fd, r0, 1.0), r0, r0);
+        // the +-1 correction needs)
+        const double r0 = __builtin_amdgcn_rcp(r.Fd);
+        r.rcp = __builtin_fma(__builtin_fma(-r.Fd, r0, 1.0), r0, r0);
+        r.thr = r.Fd * 68719476736.0;  // 2^36 * freq = K * RADIX * freq (ans_fold.hpp:89)
         return r;
     }
+    __device__ __forceinline__ void step(enc_lane& L, u32 x, const enc_ent_d& e, bool active, u32 ql, u32,
+        double Md, u8* __restrict__ out) const
+    {
+        enc_update_d(L, x, e, active, ql, Md, out);
+    }
+    __device__ __forceinline__ void init(enc_lane& L, u64 Lb) const { L.sd = (double)Lb; }
+    __device__ __forceinline__ u64 state(const enc_lane& L) const { return f64_to_u64_exact(L.sd); }
 };
 
 #define ANSX_ENC_U 8    // table entries per lane fetched ahead
@@ -775,13 +846,14 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     const u32 f = g.f, logM = B->logM;
     const u64 Lb = (u64)16 << logM;
     enc_lane L;
-    L.st = Lb;
+    tab.init(L, Lb);
     L.p = B->prelude_bytes;
+    const double Md = (double)(1u << logM);
     const u32 r = nb & 3;
     // tail symbols all go to state 0 (ans_fold.hpp:257-261)
     for (u32 t = 0; t < r; t++) {
         u32 x = src[nb - 1 - t];
-        enc_update(L, x, tab.get(f, x), ql == 0, ql, logM, out);
+        tab.step(L, x, tab.get(f, x), ql == 0, ql, logM, Md, out);
     }
     // groups of four, backwards (ans_fold.hpp:262-272): in[4g+3-q] -> state q
     const u32 G = nb >> 2;
@@ -793,7 +865,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         // ck_seg (the decoder of that segment starts with exactly these states and cursor)
         if (ck_seg && gidx == ck_g) {
             const u64 idx = (u64)b * g.nckf + (ck_seg - 1);
-            ckpt_state[idx * 4 + ql] = L.st;
+            ckpt_state[idx * 4 + ql] = tab.state(L);
             if (ql == 0) ckpt_off[idx] = L.p;
             ck_seg--;
             ck_g -= cg;
@@ -804,7 +876,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     for (u32 t = G % ANSX_ENC_XB; t > 0; t--) {
         const u32 gidx = --gi;
         u32 x = src[4 * gidx + 3 - ql];
-        enc_update(L, x, tab.get(f, x), true, ql, logM, out);
+        tab.step(L, x, tab.get(f, x), true, ql, logM, Md, out);
         record(gidx);
     }
     // Software pipeline.  Inputs are fetched XB groups (one "super-batch") ahead into registers;
@@ -826,12 +898,12 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
 #pragma unroll
                 for (int j = 0; j < ANSX_ENC_XB; j++) xb[j] = base[4 * (top - ANSX_ENC_XB - 1 - j)];
             }
-            enc_ent e1[ANSX_ENC_U];
+            typename enc_tab<LDS_TABLE>::ent e1[ANSX_ENC_U];
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, xa[j]);
 #pragma unroll
             for (int sb = 0; sb < ANSX_ENC_XB / ANSX_ENC_U; sb++) {
-                enc_ent e0[ANSX_ENC_U];
+                typename enc_tab<LDS_TABLE>::ent e0[ANSX_ENC_U];
 #pragma unroll
                 for (int j = 0; j < ANSX_ENC_U; j++) e0[j] = e1[j];
                 if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
@@ -842,12 +914,12 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                 if (ck_per_batch) {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++)
-                        enc_update(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, out);
+                        tab.step(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, Md, out);
                     record(sbtop - ANSX_ENC_U);
                 } else {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++) {
-                        enc_update(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, out);
+                        tab.step(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, Md, out);
                         record(sbtop - 1 - j);
                     }
                 }
@@ -858,7 +930,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         }
     }
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
-    st_u64_unaligned(out + L.p + 8 * ql, L.st - Lb);
+    st_u64_unaligned(out + L.p + 8 * ql, tab.state(L) - Lb);
     if (ql == 0) B->stream_bytes = L.p + 32;
 }
 

@@ -4,10 +4,10 @@ Product code: csrc/ (HIP kernels + C-ABI, built into libansx.so), include/ (C++1
 reference's methods.hpp codec structs), and this ctypes host mirror.  Nothing here imports the
 test oracle (oracle/), and there is no CPU fallback.
 """
-from ._lib import (AnsxError, DEFAULT_BLOCK_INTS, DEFAULT_CKPT_INTERVAL, FOLD, NO_CHECKPOINTS,
+from ._lib import (AnsxError, DEFAULT_BLOCK_INTS, DEFAULT_CKPT_INTERVAL, FOLD, MSB, NO_CHECKPOINTS,
                    RFOLD, SINGLE_STREAM, build_library, lib)
-from .codec import ANSfold, ANSrfold, Context, make_opts, parse_container
+from .codec import ANSfold, ANSmsb, ANSrfold, Context, make_opts, parse_container
 
-__all__ = ["ANSfold", "ANSrfold", "Context", "AnsxError", "build_library", "lib", "make_opts",
+__all__ = ["ANSfold", "ANSrfold", "ANSmsb", "MSB", "Context", "AnsxError", "build_library", "lib", "make_opts",
            "parse_container", "FOLD", "RFOLD", "SINGLE_STREAM", "NO_CHECKPOINTS",
            "DEFAULT_BLOCK_INTS", "DEFAULT_CKPT_INTERVAL"]

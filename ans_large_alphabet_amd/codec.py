@@ -131,6 +131,15 @@ class ANSrfold(_Codec):
     PREFIX = "ANSrfold"
 
 
+class ANSmsb(_Codec):
+    """methods.hpp:499-515 (include/ans_msb.hpp): the fixed-threshold MSB fold; no fidelity."""
+    KIND = L.MSB
+    PREFIX = "ANSmsb"
+
+    def __init__(self, ctx=None, block_ints=0, ckpt_interval=0):
+        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval)
+
+
 # ---------------------------------------------------------------- container parsing (host)
 
 def parse_container(buf):

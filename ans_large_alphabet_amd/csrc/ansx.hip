@@ -110,7 +110,8 @@ inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 size_t block_bound(int kind, u32 f, size_t nb)
 {
     size_t hdr = kind == ANSX_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
-    return hdr + 8 + 4 * (size_t)fold_NSP(f) + 7 * nb + 32;
+    size_t nsp = kind == ANSX_MSB ? 2048u : fold_NSP(f);
+    return hdr + 8 + 4 * nsp + 7 * nb + 32;
 }
 
 struct Plan {
@@ -122,8 +123,10 @@ struct Plan {
 
 int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
 {
-    if (kind != ANSX_FOLD && kind != ANSX_RFOLD) return ANSX_ERR_ARG;
-    if (f < 1 || f > 7) return ANSX_ERR_ARG;
+    if (kind != ANSX_FOLD && kind != ANSX_RFOLD && kind != ANSX_MSB) return ANSX_ERR_ARG;
+    if (kind == ANSX_MSB) {
+        if (f != 0) return ANSX_ERR_ARG;  // ANSmsb has no fidelity parameter (methods.hpp:499-515)
+    } else if (f < 1 || f > 7) return ANSX_ERR_ARG;
     if (n == 0) return ANSX_ERR_ARG;
     u32 bi = opts ? opts->block_ints : 0;
     u32 ck = opts ? opts->ckpt_interval : 0;
@@ -152,8 +155,10 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     g.nckf = geo_nseg(bi, ck) - 1;
     g.f = (u32)f;
     g.kind = (u32)kind;
+    g.map = kind == ANSX_MSB ? map_msb() : map_fold((u32)f);
     P->g = g;
-    P->NSP = fold_NSP((u32)f);
+    // symbol-array stride: the reference's MAX_SIGMA (ans_fold.hpp:70; ans_msb.hpp:28 has 1280)
+    P->NSP = kind == ANSX_MSB ? 2048u : fold_NSP((u32)f);
     Layout L;
     L.index_off = sizeof(ansx_container_header);
     L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
@@ -418,7 +423,8 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     memcpy(&H, h, sizeof(H));
     static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
     if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
-    if (H.kind > 1 || H.fidelity < 1 || H.fidelity > 7 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
+    if (H.kind > 2 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
+    if (H.kind == ANSX_MSB ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > 7)) return ANSX_ERR_FORMAT;
     *out = H;
     return ANSX_OK;
 }
@@ -602,6 +608,7 @@ int ansx_last_hip_error(const ansx_ctx* c) { return c ? c->last_hip : 0; }
 
 int ansx_codec_name(int kind, int f, char* buf, size_t buflen)
 {
+    if (kind == ANSX_MSB) return snprintf(buf, buflen, "ANSmsb");
     return snprintf(buf, buflen, "%s-%d", kind == ANSX_RFOLD ? "ANSrfold" : "ANSfold", f);
 }
 

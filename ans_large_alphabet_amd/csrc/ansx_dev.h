@@ -25,29 +25,38 @@ ANSX_HD u32 fold_T(u32 f) { return 1u << (f + 7); }
 ANSX_HD u32 fold_D(u32 f) { return 255u << (f - 1); }
 ANSX_HD u32 fold_NSP(u32 f) { return 1u << (f + 9); }  // symbol-array stride = reference MAX_SIGMA (ans_fold.hpp:70)
 
-// Closed form of the reference's byte-stripping loop (ans_fold.hpp:38-65): number of exception
-// bytes k and folded symbol.  Valid for all 32-bit x because T >= 256.
-ANSX_HD u32 fold_nbytes(u32 f, u32 x)
-{
-    const u32 T = fold_T(f);
-    // x >= T, x >= 256T, x >= 65536T ; 65536*T may exceed 2^32 only for f >= 9 (out of scope)
-    u32 k = (x >= T) ? 1u : 0u;
-    k += ((x >> 8) >= T) ? 1u : 0u;
-    k += ((x >> 16) >= T) ? 1u : 0u;
-    return k;
-}
-ANSX_HD u32 fold_sym(u32 f, u32 x, u32 k) { return (x >> (8 * k)) + k * fold_D(f); }
-
-// include/ans_fold.hpp:150-175
-ANSX_HD u32 unfold_nbytes(u32 f, u32 sym)
+// Byte-stripping map value -> (symbol, k exception bytes), parameterised so that one set of
+// kernels serves ANSfold<f>/ANSrfold<f> (ans_fold.hpp:38-65,150-175: thresholds T*256^j,
+// k*D symbol offset) and ANSmsb (ans_msb.hpp:41-74,159-180: thresholds 256^j inclusive, 256*k).
+//   k   = (x >= t1) + (x >= t2) + (x >= t3);        sym   = (x >> 8k) + k*D
+//   k   = (sym >= u1) + (sym >= u2) + (sym >= u3);  value = (sym - k*D) << 8k
+// This is the closed form of the reference's while-loop; valid for all 32-bit x.
+struct ansx_map {
+    u32 t1, t2, t3;
+    u32 u1, u2, u3;
+    u32 D;
+};
+ANSX_HD ansx_map map_fold(u32 f)
 {
     const u32 T = fold_T(f), D = fold_D(f);
-    u32 k = (sym >= T) ? 1u : 0u;
-    k += (sym >= T + D) ? 1u : 0u;
-    k += (sym >= T + 2 * D) ? 1u : 0u;
-    return k;
+    ansx_map m = { T, T << 8, T << 16, T, T + D, T + 2 * D, D };
+    return m;
 }
-ANSX_HD u32 unfold_value(u32 f, u32 sym, u32 k) { return (sym - k * fold_D(f)) << (8 * k); }
+ANSX_HD ansx_map map_msb()
+{
+    ansx_map m = { 257u, 65537u, (1u << 24) + 1u, 257u, 513u, 769u, 256u };
+    return m;
+}
+ANSX_HD u32 map_nbytes(const ansx_map& m, u32 x)
+{
+    return ((x >= m.t1) ? 1u : 0u) + ((x >= m.t2) ? 1u : 0u) + ((x >= m.t3) ? 1u : 0u);
+}
+ANSX_HD u32 map_sym(const ansx_map& m, u32 x, u32 k) { return (x >> (8 * k)) + k * m.D; }
+ANSX_HD u32 unmap_nbytes(const ansx_map& m, u32 sym)
+{
+    return ((sym >= m.u1) ? 1u : 0u) + ((sym >= m.u2) ? 1u : 0u) + ((sym >= m.u3) ? 1u : 0u);
+}
+ANSX_HD u32 unmap_value(const ansx_map& m, u32 sym, u32 k) { return (sym - k * m.D) << (8 * k); }
 
 // ---------------------------------------------------------------------------------------------
 // Portable log2: only IEEE +,-,*,/ and fma, identical on host and device.  Replaces glibc's
@@ -192,8 +201,9 @@ struct ansx_geo {
     u32 nblocks;
     u32 ckpt;        // restart interval in ints (0 = none)
     u32 nckf;        // restart points stored per block (stride)
-    u32 f;           // fidelity
-    u32 kind;        // 0 fold, 1 rfold
+    u32 f;           // fidelity (0 for ANSmsb)
+    u32 kind;        // 0 fold, 1 rfold, 2 msb
+    ansx_map map;    // value <-> symbol map of this codec
 };
 
 ANSX_HD u32 geo_block_n(const ansx_geo& g, u32 b)

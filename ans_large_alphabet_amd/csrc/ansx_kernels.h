@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     const u32* src = in + (u64)b * g.block_ints + start;
     for (u32 s = tid; s < NSP; s += 256) lds_hist[s] = 0;
     __syncthreads();
-    const u32 f = g.f;
+    const ansx_map mp = g.map;
     u32 lmax = 0, bad = 0;
     auto take = [&](u32 x) {
         bad |= (x >= value_limit) ? 1u : 0u;
-        u32 k = fold_nbytes(f, x);
-        u32 s = fold_sym(f, x, k);
+        u32 k = map_nbytes(mp, x);
+        u32 s = map_sym(mp, x, k);
         atomicAdd(&lds_hist[s], 1u);
         lmax = s > lmax ? s : lmax;
     };
@@ -763,11 +763,11 @@ template <bool LDS_TABLE> struct enc_tab;
 template <> struct enc_tab<false> {
     const ansx_enc_entry* t;
     typedef enc_ent ent;
-    __device__ __forceinline__ enc_ent get(u32 f, u32 x) const
+    __device__ __forceinline__ enc_ent get(const ansx_map& mp, u32 x) const
     {
         enc_ent r;
-        r.k = fold_nbytes(f, x);
-        ansx_enc_entry e = t[fold_sym(f, x, r.k)];
+        r.k = map_nbytes(mp, x);
+        ansx_enc_entry e = t[map_sym(mp, x, r.k)];
         r.freq = e.freq;
         r.base = e.base;
         r.rcp = e.rcp;
@@ -784,11 +784,11 @@ template <> struct enc_tab<false> {
 template <> struct enc_tab<true> {
     const u32* t;  // LDS
     typedef enc_ent_d ent;
-    __device__ __forceinline__ enc_ent_d get(u32 f, u32 x) const
+    __device__ __forceinline__ enc_ent_d get(const ansx_map& mp, u32 x) const
     {
         enc_ent_d r;
-        r.k = fold_nbytes(f, x);
-        const u32 e = t[fold_sym(f, x, r.k)];
+        r.k = map_nbytes(mp, x);
+        const u32 e = t[map_sym(mp, x, r.k)];
         r.Fd = (double)(e & 0xFFFFu);
         r.based = (double)(e >> 16);
         // 1/freq: hardware seed + one Newton step (relative error ~2^-50, far below the 2^-37
@@ -843,7 +843,8 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     if constexpr (LDS_TABLE) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
     else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
-    const u32 f = g.f, logM = B->logM;
+    const ansx_map f = g.map;  // value -> symbol map
+    const u32 logM = B->logM;
     const u64 Lb = (u64)16 << logM;
     enc_lane L;
     tab.init(L, Lb);
@@ -1159,7 +1160,7 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
 }
 
 template <bool RFOLD, bool STREAM_LDS>
-__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u32 f, u32 logM,
+__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, const ansx_map& f, u32 rfT, u32 logM,
     u32 mask, u64 Lb, const u32* cum, const u16* s2s, const u32* mf, u32 rflag,
     const u8* __restrict__ stream, const u32* lds_stream)
 {
@@ -1169,7 +1170,7 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
     const u32 fr = c1 - c0;
     u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - c0);  // ans_fold.hpp:218-220
     const bool rn = active && (ns_ < Lb);
-    const u32 k = unfold_nbytes(f, sym);
+    const u32 k = unmap_nbytes(f, sym);
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
     u32 total;
     const u32 incl = quad_incl_scan(c, ql, &total);
@@ -1180,9 +1181,9 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
     if (active) st = ns_;
     // exception bytes sit just below the renorm word (ans_fold.hpp:135-147)
     const u32 e = c ? ((u32)(v >> (64 - 8 * c)) & ((1u << (8 * k)) - 1u)) : 0u;
-    u32 val = unfold_value(f, sym, k) + e;
+    u32 val = unmap_value(f, sym, k) + e;
     if (RFOLD) {
-        const u32 T = fold_T(f);
+        const u32 T = rfT;
         if (rflag) val = (sym < T) ? mf[sym] : (val - T);  // ans_reorder_fold.hpp:207-219,300-301
     }
     p -= (int)total;
@@ -1192,7 +1193,7 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, u3
 // decode every segment of one block (one quad of lanes per segment)
 template <bool RFOLD, bool STREAM_LDS>
 __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u32 sbytes, u32 tid,
-    u32 nt, u32 f, u32 logM, const u32* cum, const u16* s2s, const u32* mfl, u32 rflag,
+    u32 nt, const ansx_map& f, u32 rfT, u32 logM, const u32* cum, const u16* s2s, const u32* mfl, u32 rflag,
     const u8* __restrict__ stream, const u32* lds_stream, const u64* __restrict__ ckpt_state,
     const u32* __restrict__ ckpt_off, u32* __restrict__ o)
 {
@@ -1218,7 +1219,7 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
         end = end < nfull ? end : nfull;
         if (STREAM_LDS) {
             for (u32 i = start; i < end; i += 4) {
-                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
                 o[i + ql] = val;
             }
         } else {
@@ -1235,14 +1236,14 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                     pf = ld_u32_unaligned(stream + (a & ~3));
                     pf_front -= 512;
                 }
-                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
                 o[i + ql] = val;
             }
             asm volatile("" ::"v"(pf));
         }
         if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
             for (u32 i = nfull; i < nb; i++) {
-                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
                 if (ql == 3) o[i] = val;
             }
         }
@@ -1273,8 +1274,8 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64 boff = block_off[b];
     const u8* stream = cont + payload_off + boff;
     const u32 sbytes = (u32)(block_off[b + 1] - boff);
-    const u32 f = g.f;
-    const u32 T = fold_T(f);
+    const ansx_map f = g.map;
+    const u32 T = fold_T(g.f);
     const u32 M = 1u << logM;
     // LDS carve: [cum][s2s][most-frequent table][staged stream]
     const u32 cb = ((max_ns + 2) * 4 + 15) & ~15u;
@@ -1354,7 +1355,7 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     __syncthreads();
     u32* o = outp + (u64)b * g.block_ints;
     if (st_lds)
-        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
-        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
 }

@@ -60,8 +60,9 @@ struct Runtime {
 };
 
 template <int KIND, uint32_t fidelity, uint32_t BLOCK_INTS> struct Codec {
-    static std::string name()  // methods.hpp:530-533 / 550-553
+    static std::string name()  // methods.hpp:530-533 / 550-553 / 500
     {
+        if (KIND == ANSX_MSB) return "ANSmsb";
         return std::string(KIND == ANSX_RFOLD ? "ANSrfold-" : "ANSfold-") + std::to_string(fidelity);
     }
     static ansx_opts opts()
@@ -103,6 +104,9 @@ template <int KIND, uint32_t fidelity, uint32_t BLOCK_INTS> struct Codec {
 // drop-in names (block container, library default block size)
 template <uint32_t fidelity> using ANSfoldGPU = ansx::Codec<ANSX_FOLD, fidelity, 0u>;
 template <uint32_t fidelity> using ANSrfoldGPU = ansx::Codec<ANSX_RFOLD, fidelity, 0u>;
+// ANSmsb (methods.hpp:499-515): the fixed-threshold MSB fold, same kernels, no fidelity
+using ANSmsbGPU = ansx::Codec<ANSX_MSB, 0u, 0u>;
+using ANSmsbGPUStream = ansx::Codec<ANSX_MSB, 0u, ANSX_SINGLE_STREAM>;
 // exactly one reference stream, byte-identical to ANSfold<f>::encode / ANSrfold<f>::encode
 template <uint32_t fidelity> using ANSfoldGPUStream = ansx::Codec<ANSX_FOLD, fidelity, ANSX_SINGLE_STREAM>;
 template <uint32_t fidelity> using ANSrfoldGPUStream = ansx::Codec<ANSX_RFOLD, fidelity, ANSX_SINGLE_STREAM>;

@@ -168,6 +168,7 @@ int main(int argc, char const* argv[])
             run<ANSfoldGPU<5>>(inputs);
             run<ANSrfoldGPU<1>>(inputs);
             run<ANSrfoldGPU<5>>(inputs);
+            run<ANSmsbGPU>(inputs);  // the reference runs ANSmsb in benchmark.cpp:174 / table_effectiveness.cpp:146
         } else {
             run<ANSfoldGPUStream<1>>(inputs);
             run<ANSfoldGPUStream<5>>(inputs);

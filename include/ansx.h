@@ -51,8 +51,9 @@ extern "C" {
 typedef struct ansx_ctx ansx_ctx;
 
 typedef enum {
-    ANSX_FOLD = 0, /* ANSfold<f>  */
-    ANSX_RFOLD = 1 /* ANSrfold<f> */
+    ANSX_FOLD = 0,  /* ANSfold<f>  */
+    ANSX_RFOLD = 1, /* ANSrfold<f> */
+    ANSX_MSB = 2    /* ANSmsb (include/methods.hpp:499-515 -> include/ans_msb.hpp); fidelity must be 0 */
 } ansx_kind;
 
 typedef enum {

@@ -15,6 +15,10 @@
 #define ANS_K 16ull
 #define ANS_RADIX_LOG2 32
 
+/* kind 2 = ANSmsb (include/ans_msb.hpp): same skeleton, different byte-stripping map */
+#define ANS_ORACLE_MSB 2
+#define MSB_MAX_SIGMA 1280u /* ans_msb.hpp:28 */
+
 static inline uint32_t fold_T(uint32_t f) { return 1u << (f + 7); }          /* ans_fold.hpp:43 */
 static inline uint32_t fold_D(uint32_t f) { return 255u << (f - 1); }        /* ans_fold.hpp:47 */
 static inline uint32_t fold_max_sigma(uint32_t f) { return 1u << (f + 9); }  /* ans_fold.hpp:70 */
@@ -44,6 +48,21 @@ uint32_t ans_oracle_unfold(uint32_t f, uint32_t sym, uint32_t* nbytes)
     uint32_t k = (sym - T) / D + 1;
     if (nbytes) *nbytes = k;
     return (sym - D * k) << (8 * k);
+}
+
+/* include/ans_msb.hpp:41-74 */
+static uint32_t msb_map(uint32_t x, uint32_t* nbytes)
+{
+    uint32_t k = (x > 256u) + (x > (1u << 16)) + (x > (1u << 24));
+    if (nbytes) *nbytes = k;
+    return (x >> (8 * k)) + 256u * k;
+}
+/* include/ans_msb.hpp:159-180 */
+static uint32_t msb_unmap(uint32_t sym, uint32_t* nbytes)
+{
+    uint32_t k = (sym > 256u) + (sym > 512u) + (sym > 768u);
+    if (nbytes) *nbytes = k;
+    return (sym - 256u * k) << (8 * k);
 }
 
 /* ---------------------------------------------------------------- normalisation */
@@ -410,7 +429,7 @@ static int cmp_cv(const void* a, const void* b) /* (-count, value) ascending: an
 
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n)
 {
-    size_t nsyms_max = (size_t)fold_T(f) + 3u * (size_t)fold_D(f);
+    size_t nsyms_max = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (size_t)fold_T(f) + 3u * (size_t)fold_D(f);
     size_t hdr = kind == ANS_ORACLE_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
     return hdr + 8 + 4 * nsyms_max + 8 + 7 * n + 32;
 }
@@ -419,10 +438,11 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     size_t cap, ans_oracle_info* info, size_t ckpt_interval, uint64_t* ckpt_states,
     uint32_t* ckpt_off, size_t* n_ckpt)
 {
+    if (kind == ANS_ORACLE_MSB) f = 1; /* fidelity is not a parameter of ANSmsb */
     if (n == 0 || f < 1 || f > 7) return 0; /* n == 0 never terminates in the reference (F4) */
     if (cap < ans_oracle_bound(kind, f, n)) return 0;
     const uint32_t T = fold_T(f);
-    const uint32_t MAX_SIGMA = fold_max_sigma(f);
+    const uint32_t MAX_SIGMA = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f);
     ans_oracle_info local;
     memset(&local, 0, sizeof(local));
 
@@ -497,11 +517,11 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     for (size_t i = 0; i < n; i++) {
         uint32_t mv;
         MAP_VALUE(in[i], mv);
-        uint32_t s = ans_oracle_fold(f, mv, NULL);
+        uint32_t s = kind == ANS_ORACLE_MSB ? msb_map(mv, NULL) : ans_oracle_fold(f, mv, NULL);
         freqs[s]++;
         if (s > max_sym) max_sym = s;
     }
-    if (kind == ANS_ORACLE_FOLD) {
+    if (kind != ANS_ORACLE_RFOLD) {
         for (uint32_t i = 0; i < MAX_SIGMA; i++) local.sigma += (freqs[i] != 0);
     }
     size_t nsyms = (size_t)max_sym + 1;
@@ -563,11 +583,17 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
         uint32_t x;                                                                              \
         MAP_VALUE((value), x);                                                                   \
         uint32_t off = 0;                                                                        \
-        while (x >= T) { /* ans_fold.hpp:57-61 */                                                \
-            *p++ = (uint8_t)(x & 0xFF);                                                          \
-            x >>= 8;                                                                             \
-            off += D;                                                                            \
-        }                                                                                        \
+        if (kind == ANS_ORACLE_MSB) { /* ans_msb.hpp:52-74: low bytes first, like fold */        \
+            uint32_t kk;                                                                         \
+            uint32_t sy = msb_map(x, &kk);                                                       \
+            for (uint32_t bi = 0; bi < kk; bi++) *p++ = (uint8_t)((x >> (8 * bi)) & 0xFF);       \
+            x = sy;                                                                              \
+        } else                                                                                   \
+            while (x >= T) { /* ans_fold.hpp:57-61 */                                            \
+                *p++ = (uint8_t)(x & 0xFF);                                                      \
+                x >>= 8;                                                                         \
+                off += D;                                                                        \
+            }                                                                                    \
         const enc_entry* e = &table[x + off];                                                    \
         uint64_t ub = ((uint64_t)e->freq) << (ANS_RADIX_LOG2 + 4); /* K*RADIX*freq, :89 */       \
         if ((state) >= ub) { /* :105-110 */                                                      \
@@ -628,6 +654,7 @@ typedef struct {
 int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in, uint32_t* out,
     size_t n, int ref_f3_compat)
 {
+    if (kind == ANS_ORACLE_MSB) f = 1;
     if (f < 1 || f > 7) return -1;
     const uint32_t T = fold_T(f);
     const uint8_t* p = in;
@@ -643,7 +670,7 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     }
     uint32_t max_sym_peek; /* guard against corrupt input: the alphabet has < 2^(f+9) symbols */
     vbyte_get(p, &max_sym_peek);
-    if (max_sym_peek >= fold_max_sigma(f)) return -2;
+    if (max_sym_peek >= (kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f))) return -2;
     uint32_t* nfreqs = (uint32_t*)calloc((size_t)max_sym_peek + 2, sizeof(uint32_t));
     uint32_t lg = 0;
     size_t nsyms = ans_oracle_read_prelude(p, nfreqs, &lg);
@@ -657,7 +684,7 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     uint64_t base = 0;
     for (size_t s = 0; s < nsyms; s++) {
         uint32_t k;
-        uint32_t val = ans_oracle_unfold(f, (uint32_t)s, &k);
+        uint32_t val = kind == ANS_ORACLE_MSB ? msb_unmap((uint32_t)s, &k) : ans_oracle_unfold(f, (uint32_t)s, &k);
         if (kind == ANS_ORACLE_RFOLD) {
             /* ans_reorder_fold.hpp:207-219: s < T -> most_frequent[s] + T; final "- T" at :301 */
             if (flag == 1) {

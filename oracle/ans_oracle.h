@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-enum { ANS_ORACLE_FOLD = 0, ANS_ORACLE_RFOLD = 1 };
+enum { ANS_ORACLE_FOLD = 0, ANS_ORACLE_RFOLD = 1, ANS_ORACLE_MSB_KIND = 2 /* ANSmsb, include/ans_msb.hpp; f ignored */ };
 
 typedef struct {
     uint32_t max_sym;       /* largest folded symbol in the block                         */

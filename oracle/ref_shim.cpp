@@ -27,6 +27,7 @@
 #include "ans_byte.hpp"
 #include "ans_fold.hpp"
 #include "ans_reorder_fold.hpp"
+#include "ans_msb.hpp"
 
 namespace {
 
@@ -67,9 +68,10 @@ void rfold_dec(const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
 
 extern "C" {
 
-// kind: 0 = ANSfold<f>, 1 = ANSrfold<f>
+// kind: 0 = ANSfold<f>, 1 = ANSrfold<f>, 2 = ANSmsb (methods.hpp:499-515)
 size_t ref_encode(int kind, int f, const uint32_t* in, size_t n, uint8_t* out, size_t cap)
 {
+    if (kind == 2) return ans_msb_compress(out, cap, in, n);
     if (kind == 0) {
         DISPATCH_F(fold_enc, in, n, out, cap)
     } else {
@@ -80,6 +82,10 @@ size_t ref_encode(int kind, int f, const uint32_t* in, size_t n, uint8_t* out, s
 
 void ref_decode(int kind, int f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
 {
+    if (kind == 2) {
+        ans_msb_decompress(out, n, in, nbytes);
+        return;
+    }
     if (kind == 0) {
         DISPATCH_F(fold_dec, in, nbytes, out, n)
     } else {

@@ -32,8 +32,11 @@ EXPLICIT = [  # SURVEY 8c canonical known answers + F3 triggers
     ("fold", 1, [7] * 1000),
     ("rfold", 1, [5, 1000, 5, 70000, 5, 5, 1000]),
     ("fold", 1, [(1 << 30) - 1, 0, 255, 256, 65535, 65536, 16777215, 16777216]),
+    ("msb", 0, [(1 << 30) - 1, 0, 255, 256, 257, 65535, 65536, 65537, 16777215, 16777216, 16777217]),
+    ("msb", 0, [5]),
+    ("msb", 0, [300, 300, 7]),
 ]
-KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD}
+KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD, "msb": ol.MSB}
 
 
 def entry(kind_name, f, data, verbatim, name=None, seed=None):
@@ -69,8 +72,8 @@ def main():
     small, large = [], []
     for k, f, d in EXPLICIT:
         small.append(entry(k, f, d, True))
-    for k in ("fold", "rfold"):
-        for f in (1, 3, 5):
+    for k, flist in (("fold", (1, 3, 5)), ("rfold", (1, 3, 5)), ("msb", (0,))):
+        for f in flist:
             for fam in FAMILIES:
                 for n in SMALL_N:
                     if n > 313 and fam not in ("uniform256", "zipf20s1.2", "geom0.01", "sparse_large"):

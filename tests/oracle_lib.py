@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-FOLD, RFOLD = 0, 1
+FOLD, RFOLD, MSB = 0, 1, 2
 
 
 class OracleInfo(C.Structure):

@@ -37,6 +37,7 @@ def test_names_follow_methods_hpp(A):
     assert A.ANSfold(1).name() == "ANSfold-1"
     assert A.ANSfold(5).name() == "ANSfold-5"
     assert A.ANSrfold(3).name() == "ANSrfold-3"
+    assert A.ANSmsb().name() == "ANSmsb"  # methods.hpp:500
 
 
 def test_bound_and_argument_validation(A):
@@ -47,7 +48,9 @@ def test_bound_and_argument_validation(A):
             assert b >= 7 * (1 << 20)
     assert L.ansx_bound(A.FOLD, 0, 100, None) == 0      # fidelity out of range
     assert L.ansx_bound(A.FOLD, 8, 100, None) == 0
-    assert L.ansx_bound(2, 1, 100, None) == 0           # unknown codec
+    assert L.ansx_bound(3, 1, 100, None) == 0           # unknown codec
+    assert L.ansx_bound(A.MSB, 1, 100, None) == 0       # ANSmsb takes no fidelity
+    assert L.ansx_bound(A.MSB, 0, 100, None) > 700
     assert L.ansx_bound(A.FOLD, 1, 0, None) == 0        # n == 0 (reference never terminates)
     o = A.make_opts(block_ints=1001)                    # blocks must be a multiple of 4 ints
     assert L.ansx_bound(A.FOLD, 1, 100, C.byref(o)) == 0

@@ -17,7 +17,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD}
+KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD, "msb": ol.MSB}
 
 
 @pytest.fixture(scope="module")
@@ -43,6 +43,8 @@ def ctx(A, oracle_built):
 
 
 def codec_for(A, ctx, kind, f, **kw):
+    if kind == ol.MSB:
+        return A.ANSmsb(ctx=ctx, **kw)
     cls = A.ANSfold if kind == ol.FOLD else A.ANSrfold
     return cls(f, ctx=ctx, **kw)
 
@@ -352,3 +354,23 @@ def test_rfold_large_blocks_and_whole_list(A, ctx, f):
         exp, info, _, _ = ol.oracle_encode(ol.RFOLD, f, data)
         assert np.array_equal(s, exp), (f, fam)
         assert np.array_equal(codec.decode(s, n), data)
+
+
+@pytest.mark.parametrize("fam", FAMS)
+def test_msb_blocks_match_oracle(A, ctx, fam):
+    """ANSmsb: same kernels, fixed-threshold map; per-block parity + round trip."""
+    n = 70001
+    data = ol.gen_inputs(fam, n, seed=41)
+    data[:11] = np.array([0, 255, 256, 257, 65535, 65536, 65537, (1 << 24) - 1, 1 << 24, (1 << 24) + 1,
+                          (1 << 30) - 1], dtype=np.uint32)
+    codec = codec_for(A, ctx, ol.MSB, 0, block_ints=16384, ckpt_interval=1024)
+    assert codec.name() == "ANSmsb"
+    cont = codec.encode(data)
+    check_container(A, cont, data, ol.MSB, 0, 16384, 1024)
+    assert np.array_equal(codec.decode(cont, n), data)
+    if fam in ("zipf20s1.2", "boundaries"):
+        codec = codec_for(A, ctx, ol.MSB, 0, block_ints=A.SINGLE_STREAM)
+        s = codec.encode(data[:9001])
+        exp, _, _, _ = ol.oracle_encode(ol.MSB, 0, data[:9001])
+        assert np.array_equal(s, exp)
+        assert np.array_equal(codec.decode(exp, 9001), data[:9001])

@@ -18,7 +18,7 @@ import pytest
 import oracle_lib as ol
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD}
+KIND = {"fold": ol.FOLD, "rfold": ol.RFOLD, "msb": ol.MSB}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -85,7 +85,8 @@ def _load(name):
 
 def test_golden_small():
     gold = _load("small.json")
-    assert len(gold) > 400
+    assert len(gold) > 500
+    assert sum(1 for e in gold if e["kind"] == "msb") > 60
     for e in gold:
         data = np.array(e["input"], dtype=np.uint32)
         s, info, _, _ = ol.oracle_encode(KIND[e["kind"]], e["f"], data)
@@ -261,3 +262,24 @@ def test_checkpoints_restart_points():
     # the last 32 bytes hold state - 16M of the whole-block encoder = restart point of segment 0
     tail = np.frombuffer(s[-32:].tobytes(), dtype=np.uint64)
     assert np.array_equal(tail + np.uint64(16 * M), np.array(list(info.final_states), dtype=np.uint64))
+
+
+needs_ref2 = pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built")
+
+
+@needs_ref2
+def test_msb_streams_vs_reference():
+    """ANSmsb (include/ans_msb.hpp, methods.hpp:499-515): restatement vs the compiled reference."""
+    edge = np.array([0, 255, 256, 257, 65535, 65536, 65537, (1 << 24) - 1, 1 << 24, (1 << 24) + 1,
+                     (1 << 30) - 1], dtype=np.uint32)
+    for fam in ["uniform256", "uniform20", "geom0.01", "zipf20s1.2", "sparse_large", "boundaries"]:
+        for n in (1, 4, 6, 999, 20000):
+            d = ol.gen_inputs(fam, n, seed=5 + n)
+            if n >= 999:
+                d[:edge.size] = edge
+            s, info, _, _ = ol.oracle_encode(ol.MSB, 0, d)
+            for libname in ("libans_ref.so", "libans_ref_pattern.so"):
+                r = ol.ref_encode(ol.MSB, 0, d, libname)
+                assert len(r) == len(s) and np.array_equal(ol.canonicalize(r, info), s), (fam, n, libname)
+            assert np.array_equal(ol.ref_decode(ol.MSB, 0, s, n), d)
+            assert np.array_equal(ol.oracle_decode(ol.MSB, 0, s, n), d)

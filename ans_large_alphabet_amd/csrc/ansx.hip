@@ -402,6 +402,12 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     return ANSX_OK;
 }
 
+__global__ void k_selftest_log2(const double* __restrict__ in, double* __restrict__ out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ansx_log2_portable(in[i]);
+}
+
 __global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 payload_bytes,
     u32* __restrict__ gflags)
 {
@@ -760,5 +766,21 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
 }
 
 double ansx_host_log2(double x) { return ansx_log2_portable(x); }
+
+int ansx_selftest_log2(ansx_ctx* c, const double* in, double* out, size_t n)
+{
+    if (!c || !in || !out || n == 0) return ANSX_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->stage_in, n * 8))) return rc;
+    if ((rc = ensure(c, c->stage_out, n * 8))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->stage_in.p, in, n * 8, hipMemcpyHostToDevice, s));
+    LAUNCH(c, "k_selftest_log2", k_selftest_log2, (n + 255) / 256, 256, 0, s, (const double*)c->stage_in.p,
+        (double*)c->stage_out.p, (u64)n);
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ANSX_OK;
+}
 
 }  // extern "C"

@@ -139,6 +139,9 @@ size_t ansx_workspace_bytes(const ansx_ctx* ctx);
 
 /* Host evaluation of the portable log2 used by the device normaliser (unit tests only). */
 double ansx_host_log2(double x);
+/* The same function evaluated on the DEVICE for n inputs (host arrays): the normaliser relies on
+ * host and device results being bit-identical. */
+int ansx_selftest_log2(ansx_ctx* ctx, const double* in, double* out, size_t n);
 
 #ifdef __cplusplus
 }

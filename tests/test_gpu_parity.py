@@ -207,6 +207,26 @@ def test_errors(A, ctx):
     assert np.array_equal(codec.decode(cont, data.size), data)
 
 
+def test_device_log2_bit_identical_to_host(A, ctx):
+    """ansx_log2_portable evaluated on the device equals the host evaluation bit for bit on the
+    value classes the normaliser feeds it: p = f/n and q = S/2^k."""
+    import math
+
+    rng = np.random.default_rng(3)
+    n_ = rng.integers(1, 1 << 24, size=40000).astype(np.float64)
+    f_ = np.minimum(rng.integers(1, 1 << 24, size=40000), n_).astype(np.float64)
+    xs = np.concatenate([f_ / n_, rng.integers(1, 65535, size=40000) / np.exp2(rng.integers(1, 20, size=40000)),
+                         np.exp2(-np.arange(0, 40.0)), [1.0, 0.5, 0.999999999, 1e-9]]).astype(np.float64)
+    out = np.zeros_like(xs)
+    st = A.lib().ansx_selftest_log2(ctx.handle, xs.ctypes.data, out.ctypes.data, xs.size)
+    assert st == 0
+    host = np.array([A.lib().ansx_host_log2(float(x)) for x in xs])
+    assert np.array_equal(out.view(np.uint64), host.view(np.uint64))
+    libm = np.array([math.log2(float(x)) for x in xs])
+    rel = np.abs(out - libm) / np.maximum(np.abs(libm), 1e-300)
+    assert rel[libm != 0].max() <= 2.3e-16  # within 1 ulp of glibc
+
+
 def test_device_log2_matches_host_portable_log2(A, ctx):
     """The normaliser's log2 must be the same function on host and device; exercised indirectly:
     blocks whose XH lands near the threshold would flip otherwise.  Direct check through a

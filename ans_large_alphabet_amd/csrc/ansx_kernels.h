@@ -132,6 +132,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 {
     extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
     __shared__ u32 cnt[ANSX_VMAX];
+    __shared__ u16 cnt0[ANSX_VMAX];  // number of symbols per frequency value (before the scan)
     __shared__ double terms[512];
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         u32 run = incl - loc;
         for (u32 i = 0; i < per; i++) {
             u32 t = cnt[lane * per + i];
+            cnt0[lane * per + i] = (u16)(t > 0xFFFFu ? 0xFFFFu : t);
             cnt[lane * per + i] = run;
             run += t;
         }
@@ -194,12 +196,21 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         const u32 s = s0 + lane;
         const u32 fr = s < ns ? hrow[s] : 0u;
         const bool small = fr != 0 && fr < ANSX_VMAX;
-        unsigned long long todo = __ballot(small);
+        // a frequency value that occurs once in the whole block needs no ranking: its symbol goes
+        // to the start of its bin (this covers nearly all "hot" symbols, whose values are all
+        // distinct and would otherwise cost one loop iteration each)
+        const bool uniq = small && cnt0[fr] == 1;
+        if (uniq) {
+            const u32 pos = cnt[fr];
+            oF[pos] = fr;
+            oS[pos] = (u16)s;
+        }
+        unsigned long long todo = __ballot(small && !uniq);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const u32 v0 = (u32)__builtin_amdgcn_readlane((int)fr, leader);  // leader is wave-uniform
-            const unsigned long long m = __ballot(small && fr == v0);
-            if (small && fr == v0) {
+            const unsigned long long m = __ballot(small && !uniq && fr == v0);
+            if (small && !uniq && fr == v0) {
                 const u32 pos = cnt[v0] + (u32)__popcll(m & ((1ull << lane) - 1ull));
                 oF[pos] = fr;
                 oS[pos] = (u16)s;

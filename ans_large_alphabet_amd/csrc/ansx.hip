@@ -42,7 +42,7 @@ struct ansx_ctx {
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
-    DevBuf hist, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
+    DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
         stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
 };
@@ -275,8 +275,16 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if (chunk & 3u) chunk = (chunk + 3u) & ~3u;
     const u32 cpb = (g.block_ints + chunk - 1) / chunk;
     if (cpb > 1) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)NB * NSP * 4, s));
+    // blocks that fit one histogram workgroup (the normal case) get their entropy terms from K1
+    // and the in-order sum from K2b; longer blocks keep both in K2a
+    const bool h_deferred = (cpb == 1);
+    double* hterm = nullptr;
+    if (h_deferred) {
+        if ((rc = ensure(c, c->hterm, (size_t)NB * NSP * 8))) return rc;
+        hterm = (double*)c->hterm.p;
+    }
     LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * 4, s, src, g, chunk, cpb, NSP,
-        hist, blk, gflags, 1u << 30);
+        hist, hterm, blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4;
@@ -286,7 +294,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if ((size_t)NSP * 8 + 64 > 48 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
-    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, hist,
+    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
         (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch
@@ -297,7 +305,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
             0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
-            (u16*)c->attS.p, (u32*)c->attMeta.p);
+            (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)hterm);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
             (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);
@@ -581,7 +589,7 @@ void ansx_destroy(ansx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+    DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
         &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
     for (DevBuf* b : bufs)
@@ -757,7 +765,7 @@ int ansx_profile_get(ansx_ctx* c, ansx_kernel_time* out, int max_entries, int* c
 size_t ansx_workspace_bytes(const ansx_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = { &c->hist, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+    const DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
         &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
     size_t t = 0;

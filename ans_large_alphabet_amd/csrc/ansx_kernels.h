@@ -49,8 +49,8 @@ enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 // loads.  Replaces the first pass of ans_fold_encode<f>::create (ans_fold.hpp:74-78).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
-    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, ansx_blk* __restrict__ blk,
-    u32* __restrict__ gflags, u32 value_limit)
+    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm,
+    ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
 {
     extern __shared__ u32 lds_hist[];
     const u32 tid = threadIdx.x;
@@ -88,7 +88,21 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     __syncthreads();
     u32* h = hist + (u64)b * NSP;
     if (cpb == 1) {
-        for (u32 s = tid; s < NSP; s += 256) h[s] = lds_hist[s];
+        // the block's histogram is complete here: also emit the entropy terms p*log2(p)
+        // (util.hpp:276-279) for the in-order sum taken later by k_scale_attempts; an absent
+        // symbol contributes +0.0, which leaves that sum (never -0.0) unchanged
+        const double nd = (double)nb;
+        double* ht = hterm + (u64)b * NSP;
+        for (u32 s = tid; s < NSP; s += 256) {
+            const u32 fr = lds_hist[s];
+            h[s] = fr;
+            double t = 0.0;
+            if (fr) {
+                const double p = (double)fr / nd;
+                t = p * ansx_log2_portable(p);
+            }
+            ht[s] = t;
+        }
     } else {
         for (u32 s = tid; s < NSP; s += 256) {
             u32 v = lds_hist[s];
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 // drain every outstanding global store (vmcnt(0)) at each call.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap,
+__global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk)
 {
@@ -235,7 +249,8 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     // entropy, util.hpp:271-282
     const double nd = (double)total;
     double acc = 0.0;
-    for (u32 base = 0; base < ns; base += 512) {
+    // h_deferred: the terms were produced by k_fold_hist and are summed by k_scale_attempts
+    for (u32 base = 0; base < (h_deferred ? 0u : ns); base += 512) {
         wave_lds_sync();
         for (u32 u = lane; u < 512; u += 64) {
             u32 i = base + u;
@@ -287,13 +302,33 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u32* __restrict__ sortF, const u16* __restrict__ sortSym,
-    const ansx_blk* __restrict__ blk, u16* __restrict__ attS, u32* __restrict__ attMeta)
+    ansx_blk* __restrict__ blk, u16* __restrict__ attS, u32* __restrict__ attMeta,
+    const double* __restrict__ hterm)
 {
     const u32 gid = blockIdx.x * 256 + threadIdx.x;
     const u32 b = gid / ANSX_ATTEMPTS, t = gid % ANSX_ATTEMPTS;
     if (b >= g.nblocks) return;
     const ansx_blk B = blk[b];
     if (B.resolved) return;
+    if (hterm != nullptr && batch == 0 && t == 0) {
+        // entropy H = -sum p*log2(p), left to right in index order (util.hpp:271-282); the terms
+        // come from k_fold_hist.  One lane per block, 8 blocks per wave in parallel.
+        const double* ht = hterm + (u64)b * NSP;
+        const u32 ns0 = B.max_sym + 1;
+        double acc = 0.0;
+        u32 i = 0;
+        for (; i + 4 <= ns0; i += 4) {
+            const double t0 = ht[i], t1 = ht[i + 1], t2 = ht[i + 2], t3 = ht[i + 3];
+            acc = acc + t0;
+            acc = acc + t1;
+            acc = acc + t2;
+            acc = acc + t3;
+        }
+        for (; i < ns0; i++) acc = acc + ht[i];
+        const double H = -acc;
+        blk[b].H = H;
+        blk[b].thr = H * (1.0 + (double)1 / (double)1000);  // ans_util.hpp:124
+    }
     const u32 T = batch * ANSX_ATTEMPTS + t;
     const u32 sh = B.m0_log2 + T;
     u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;

@@ -370,14 +370,31 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
     u32 threads = (u32)rup((size_t)nseg * 4, 64);
     if (threads > 256) threads = 256;
+    const size_t mfb = RF ? (size_t)T * 4 : 0;
+    const size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
+    const size_t LDS_LIMIT = 150 * 1024;
+    // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
+    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + rup((size_t)max_ns * 4, 16)
+        + rup((size_t)max_ns * 2, 16) + mfb;
+    if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !getenv("ANSX_DECODE_TABLE")) {
+        size_t lds = rs_tables;
+        u32 stream_cap = 0;
+        if (rs_tables + want_stream <= 52 * 1024) {
+            lds += want_stream;
+            stream_cap = (u32)want_stream;
+        }
+        if (lds > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_decode", (k_decode_rank<RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
+            ck_off, payload_off, d_out, maxM, max_ns, stream_cap, (const u32*)c->dec_cum.p,
+            (const uint4*)c->dec_info.p, gflags);
+        return ANSX_OK;
+    }
+    // frames above 2^16 (or forced): slot -> symbol table form, in LDS if it fits, else in HBM
     const size_t cb = rup(((size_t)max_ns + 2) * 4, 16);
     const size_t s2sb = rup((size_t)maxM * 2, 16);
-    const size_t mfb = RF ? (size_t)T * 4 : 0;
     const size_t tables = cb + s2sb + mfb;
-    const size_t LDS_LIMIT = 150 * 1024;
-    // stage the block stream in LDS when (tables + stream) still leaves >= 3 workgroups per CU
-    size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
-    if (getenv("ANSX_NO_STREAM_LDS")) want_stream = (size_t)1 << 30;  // experiment switch
     if (tables <= LDS_LIMIT) {
         size_t lds = tables;
         u32 stream_cap = 0;
@@ -388,7 +405,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         if (lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_decode<true, RF>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LAUNCH(c, "k_decode", (k_decode<true, RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
+        LAUNCH(c, "k_decode_table", (k_decode<true, RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
             ck_state, ck_off, payload_off, d_out, maxM, max_ns, stream_cap, (u16*)nullptr,
             (u32*)c->dec_cum.p, (const uint4*)c->dec_info.p, gflags);
     } else {

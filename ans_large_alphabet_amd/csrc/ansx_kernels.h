@@ -1205,16 +1205,52 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
     }
 }
 
-template <bool RFOLD, bool STREAM_LDS>
-__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, const ansx_map& f, u32 rfT, u32 logM,
-    u32 mask, u64 Lb, const u32* cum, const u16* s2s, const u32* mf, u32 rflag,
-    const u8* __restrict__ stream, const u32* lds_stream)
+// slot -> (symbol, freq, base) lookups of the decoder.
+//  dec_lut_table: the reference's layout idea (ans_fold.hpp:190-204) in 2 bytes per slot: a
+//                 slot -> symbol array plus the cumulative table (any frame size; arrays may
+//                 live in LDS or HBM).
+//  dec_lut_rank : rank/select form, ~(M/4 + 6 nsyms) bytes instead of 2M + 4 nsyms: a bitmap with
+//                 one bit per slot that starts a symbol, interleaved with the running popcount
+//                 before each 32-bit word; rank(slot) = v_bcnt(word & mask, prefix) - 1 indexes
+//                 compact per-present-symbol entries (base << 16 | freq) and symbol ids.  Still
+//                 two dependent LDS reads per step, but 6 instead of 4 workgroups fit a CU and
+//                 frames up to 2^16 keep their tables (and the staged stream) in LDS.
+struct dec_lut_table {
+    const u32* cum;
+    const u16* s2s;
+    __device__ __forceinline__ void get(u32 slot, u32& sym, u32& fr, u32& base) const
+    {
+        sym = s2s[slot];
+        const u32 c0 = cum[sym], c1 = cum[sym + 1];
+        fr = c1 - c0;
+        base = c0;
+    }
+};
+struct dec_lut_rank {
+    const uint2* bwp;  // {bitmap word, set bits before it}
+    const u32* ent;    // per present symbol: base << 16 | freq
+    const u16* psym;   // per present symbol: symbol id
+    __device__ __forceinline__ void get(u32 slot, u32& sym, u32& fr, u32& base) const
+    {
+        const uint2 wp = bwp[slot >> 5];
+        const u32 m = wp.x & (0xFFFFFFFFu >> (31u - (slot & 31u)));
+        const u32 r = (u32)__builtin_popcount(m) + wp.y - 1u;
+        const u32 e = ent[r];
+        sym = psym[r];
+        fr = e & 0xFFFFu;
+        base = e >> 16;
+    }
+};
+
+template <bool RFOLD, bool STREAM_LDS, typename LUT>
+__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, const ansx_map& f, u32 rfT,
+    u32 logM, u32 mask, u64 Lb, const LUT& lut, const u32* mf, u32 rflag, const u8* __restrict__ stream,
+    const u32* lds_stream)
 {
     const u32 slot = (u32)st & mask;
-    const u32 sym = s2s[slot];
-    const u32 c0 = cum[sym], c1 = cum[sym + 1];
-    const u32 fr = c1 - c0;
-    u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - c0);  // ans_fold.hpp:218-220
+    u32 sym, fr, base;
+    lut.get(slot, sym, fr, base);
+    u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - base);  // ans_fold.hpp:218-220
     const bool rn = active && (ns_ < Lb);
     const u32 k = unmap_nbytes(f, sym);
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
@@ -1237,9 +1273,9 @@ __device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, co
 }
 
 // decode every segment of one block (one quad of lanes per segment)
-template <bool RFOLD, bool STREAM_LDS>
+template <bool RFOLD, bool STREAM_LDS, typename LUT>
 __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u32 sbytes, u32 tid,
-    u32 nt, const ansx_map& f, u32 rfT, u32 logM, const u32* cum, const u16* s2s, const u32* mfl, u32 rflag,
+    u32 nt, const ansx_map& f, u32 rfT, u32 logM, const LUT& lut, const u32* mfl, u32 rflag,
     const u8* __restrict__ stream, const u32* lds_stream, const u64* __restrict__ ckpt_state,
     const u32* __restrict__ ckpt_off, u32* __restrict__ o)
 {
@@ -1265,7 +1301,7 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
         end = end < nfull ? end : nfull;
         if (STREAM_LDS) {
             for (u32 i = start; i < end; i += 4) {
-                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
                 o[i + ql] = val;
             }
         } else {
@@ -1282,26 +1318,165 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                     pf = ld_u32_unaligned(stream + (a & ~3));
                     pf_front -= 512;
                 }
-                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
                 o[i + ql] = val;
             }
             asm volatile("" ::"v"(pf));
         }
         if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
             for (u32 i = nfull; i < nb; i++) {
-                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, rfT, logM, mask, Lb, cum, s2s, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
                 if (ql == 3) o[i] = val;
             }
         }
     }
 }
 
-// ---- K8: one workgroup per block.  Loads the parsed table (coalesced), builds the
-// slot -> symbol table, stages the block's stream in LDS when it fits, then one quad of lanes
-// per segment decodes forward from its restart point.
+// stage the block's stream in LDS: byte a of the stream -> LDS byte a + 8 (8 guard bytes in front)
+__device__ __forceinline__ void dec_stage_stream(u32* lds_stream, const u8* __restrict__ stream, u32 sbytes,
+    u32 tid, u32 nt)
+{
+    const u32 nw = (sbytes + 3) >> 2;
+    for (u32 w = tid; w < nw; w += nt) lds_stream[w + 2] = ld_u32_unaligned(stream + 4 * (u64)w);
+    if (tid < 2) lds_stream[tid] = 0;
+    if (tid < 2) lds_stream[nw + 2 + tid] = 0;
+}
+
+// ---- K8: one workgroup per block.  Builds the decoder tables, stages the block's stream in LDS
+// when it fits, then one quad of lanes per segment decodes forward from its restart point.
 // (Measured alternatives on MI355X, 256 Mi ints: no staging 1.56 ms; whole-stream staging 1.38 ms;
 // a 512-byte per-quad ring refilled through registers 1.62 ms -- more occupancy, but every refill
 // waits on the in-order vmcnt behind the outstanding output stores.)
+//
+// k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
+template <bool RFOLD>
+__global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
+    u32 max_ns, u32 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
+    u32* __restrict__ gflags)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ u32 sh_bad;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 b = blockIdx.x;
+    const uint4 bi = binfo[b];
+    if (bi.w) return;  // parse error already flagged
+    const u32 ns = bi.x, logM = bi.y, rflag = bi.z;
+    const u32 nb = geo_block_n(g, b);
+    const u64 boff = block_off[b];
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const ansx_map f = g.map;
+    const u32 T = fold_T(g.f);
+    const u32 M = 1u << logM;
+    // LDS carve: [bitmap+prefix][entries][symbol ids][most-frequent table][staged stream]
+    const u32 wmax = maxM >= 32 ? maxM / 32 : 1;
+    u32 off = 0;
+    uint2* bwp = (uint2*)(smem + off);
+    off += (wmax * 8 + 15) & ~15u;
+    u32* ent = (u32*)(smem + off);
+    off += (max_ns * 4 + 15) & ~15u;
+    u16* psym = (u16*)(smem + off);
+    off += (max_ns * 2 + 15) & ~15u;
+    u32* mfl = nullptr;
+    if (RFOLD) {
+        mfl = (u32*)(smem + off);
+        off += 4 * T;
+    }
+    u32* lds_stream = (u32*)(smem + off);
+    const u32 W = M >= 32 ? M / 32 : 1;
+    for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
+    if (tid == 0) sh_bad = 0;
+    if (RFOLD && rflag) {
+        for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
+    }
+    const bool st_lds = (sbytes + 24 <= stream_cap);
+    if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
+    __syncthreads();
+    // wave 0: frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1),
+    // compaction of the present symbols, running base, start-of-symbol bitmap
+    if (tid < 64) {
+        const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
+        u32 carryF = 0, carryP = 0, bad = 0;
+        for (u32 s0 = 0; s0 < ns; s0 += 64) {
+            const u32 s = s0 + tid;
+            u32 fr = 0;
+            if (s < ns) {
+                const u32 cur = gc[s + 1];
+                const u32 prv = s ? gc[s] + 1u : 0u;
+                fr = cur - prv;
+                if (cur < prv || fr > M || fr > 0xFFFFu) {  // entries hold 16-bit freq and base
+                    bad = 1;
+                    fr = 0;
+                }
+            }
+            const u32 pres = fr ? 1u : 0u;
+            u32 incF = fr, incP = pres;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 tF = __shfl_up(incF, d), tP = __shfl_up(incP, d);
+                if ((int)tid >= d) {
+                    incF += tF;
+                    incP += tP;
+                }
+            }
+            const u32 base = carryF + incF - fr;
+            if (pres) {
+                if (base < M && base + fr <= M) {
+                    const u32 r = carryP + incP - 1;
+                    ent[r] = (base << 16) | fr;
+                    psym[r] = (u16)s;
+                    atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
+                } else {
+                    bad = 1;
+                }
+            }
+            carryF += __shfl(incF, 63);
+            carryP += __shfl(incP, 63);
+        }
+        if (carryF != M) bad = 1;
+        if (__ballot(bad != 0) != 0) {
+            if (tid == 0) {
+                sh_bad = 1;
+                atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+            }
+        }
+    }
+    __syncthreads();
+    if (sh_bad) return;
+    if (tid < 64) {  // running popcount before every bitmap word
+        const u32 per = (W + 63) / 64;
+        const u32 lo = tid * per;
+        u32 loc = 0;
+        for (u32 i = 0; i < per; i++)
+            if (lo + i < W) loc += (u32)__builtin_popcount(bwp[lo + i].x);
+        u32 incl = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if ((int)tid >= d) incl += t;
+        }
+        u32 run = incl - loc;
+        for (u32 i = 0; i < per; i++)
+            if (lo + i < W) {
+                bwp[lo + i].y = run;
+                run += (u32)__builtin_popcount(bwp[lo + i].x);
+            }
+    }
+    __syncthreads();
+    dec_lut_rank lut;
+    lut.bwp = bwp;
+    lut.ent = ent;
+    lut.psym = psym;
+    u32* o = outp + (u64)b * g.block_ints;
+    if (st_lds)
+        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+    else
+        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+}
+
+// k_decode: slot -> symbol table form, any frame size; tables in LDS (LDS_TAB) or in HBM.
 template <bool LDS_TAB, bool RFOLD>
 __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
@@ -1359,12 +1534,7 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
     }
     const bool st_lds = (sbytes + 24 <= stream_cap);
-    if (st_lds) {  // byte a of the stream -> LDS byte a + 8 (8 guard bytes in front)
-        const u32 nw = (sbytes + 3) >> 2;
-        for (u32 w = tid; w < nw; w += nt) lds_stream[w + 2] = ld_u32_unaligned(stream + 4 * (u64)w);
-        if (tid < 2) lds_stream[tid] = 0;
-        if (tid < 2) lds_stream[nw + 2 + tid] = 0;
-    }
+    if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
     __threadfence_block();
     __syncthreads();
     {  // validation: monotone and sums to M
@@ -1399,9 +1569,12 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     }
     __threadfence_block();
     __syncthreads();
+    dec_lut_table lut;
+    lut.cum = cum;
+    lut.s2s = s2s;
     u32* o = outp + (u64)b * g.block_ints;
     if (st_lds)
-        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
-        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, cum, s2s, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
 }

@@ -256,7 +256,7 @@ def main():
         avg_ms = kernels[dom]["avg_ms"]
         # algorithmic bytes per launch: the encoder reads 4 B/int and writes c,
         # the decoder reads c and writes 4; other kernels are priced by what they must touch
-        alg = {"k_encode": (4 + c_bytes) * n, "k_encode_gtab": (4 + c_bytes) * n, "k_decode": (c_bytes + 4) * n, "k_decode_gtab": (c_bytes + 4) * n,
+        alg = {"k_encode": (4 + c_bytes) * n, "k_encode_gtab": (4 + c_bytes) * n, "k_decode": (c_bytes + 4) * n, "k_decode_gtab": (c_bytes + 4) * n, "k_decode_table": (c_bytes + 4) * n,
                "k_fold_hist": 4.0 * n, "k_compact": 2 * c_bytes * n, "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -379,7 +379,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !getenv("ANSX_DECODE_TABLE")) {
         size_t lds = rs_tables;
         u32 stream_cap = 0;
-        if (rs_tables + want_stream <= 52 * 1024) {
+        if (rs_tables + want_stream <= 52 * 1024 && !getenv("ANSX_NO_STREAM_LDS")) {
             lds += want_stream;
             stream_cap = (u32)want_stream;
         }

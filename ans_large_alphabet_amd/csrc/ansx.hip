@@ -326,7 +326,9 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     u32* ck_off = P.plain ? nullptr : (u32*)(d_out + P.lay.ckoff_off);
     const u32 lds_stride = max_ns | 1u;  // odd stride spreads the 16 tables over the banks
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
-    if (max_logM <= 16 && enc_lds <= 40 * 1024) {
+    // (its emitted-byte stores go through a buffer descriptor spanning the wave's 16 scratch slots:
+    // 31-bit offsets)
+    if (max_logM <= 16 && enc_lds <= 40 * 1024 && (u64)scr_stride * 16 < 0x7FFFFF00ull) {
         LAUNCH(c, "k_encode", (k_encode<true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);

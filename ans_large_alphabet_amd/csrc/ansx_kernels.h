@@ -797,6 +797,42 @@ __device__ __forceinline__ void enc_update_d(enc_lane& L, u32 x, const enc_ent_d
     L.p += total;
 }
 
+// Branch-free form of the same step for the pipelined main loop.  hipcc keeps an
+// s_and_saveexec / s_cbranch_execz / s_or_b64 region around every predicated global store (VMEM
+// is never if-converted), i.e. 4 branches and 8 tiny basic blocks per step; a lone wave per SIMD
+// pays each branch as an issue bubble and the scheduler cannot move the independent table /
+// fold work of later steps into the stalls of the state chain.  Raw buffer stores make the
+// predicate part of the ADDRESS instead: a lane with nothing to write gets offset 2^31, beyond
+// num_records, and the hardware drops the access.  3 stores per step: the low two exception
+// bytes (k >= 2), the top exception byte (k odd), the renormalisation word.
+#define ANSX_BUF_OOB 0x80000000u
+__device__ __forceinline__ void enc_update_nb(enc_lane& L, u32 x, const enc_ent_d e, u32 ql, double Md,
+    __amdgpu_buffer_rsrc_t rsrc, u32 obase)
+{
+    const u32 k = e.k;
+    const u32 eb = x & ((1u << (8 * k)) - 1u);
+    const double sd = L.sd;
+    const bool rn = sd >= e.thr;
+    const double hi = __builtin_trunc(sd * (1.0 / 4294967296.0));
+    const double wd = __builtin_fma(-hi, 4294967296.0, sd);
+    const u32 w = (u32)wd;
+    const double s0 = rn ? hi : sd;
+    double qd = __builtin_trunc(s0 * e.rcp);
+    double rd = __builtin_fma(-qd, e.Fd, s0);
+    const double adj = (rd < 0.0) ? -1.0 : ((rd >= e.Fd) ? 1.0 : 0.0);
+    qd = qd + adj;
+    rd = __builtin_fma(-adj, e.Fd, rd);
+    L.sd = __builtin_fma(qd, Md, rd + e.based);
+    const u32 c = k + (rn ? 4u : 0u);
+    u32 total;
+    const u32 incl = quad_incl_scan(c, ql, &total);
+    const u32 a = obase + L.p + (incl - c);
+    __builtin_amdgcn_raw_buffer_store_b16((u16)eb, rsrc, (k >= 2) ? a : ANSX_BUF_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b8((u8)(eb >> (8 * (k - 1) & 31)), rsrc, (k & 1) ? a + k - 1 : ANSX_BUF_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, rn ? a + k : ANSX_BUF_OOB, 0, 0);
+    L.p += total;
+}
+
 __device__ __forceinline__ u64 f64_to_u64_exact(double d)  // d is an integer in [0, 2^53)
 {
     const double hi = __builtin_trunc(d * (1.0 / 4294967296.0));
@@ -824,6 +860,11 @@ template <> struct enc_tab<false> {
     {
         enc_update(L, x, e, active, ql, logM, out);
     }
+    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent& e, u32 ql, u32 logM, double,
+        __amdgpu_buffer_rsrc_t, u32, u8* __restrict__ out) const
+    {
+        enc_update(L, x, e, true, ql, logM, out);
+    }
     __device__ __forceinline__ void init(enc_lane& L, u64 Lb) const { L.st = Lb; }
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return L.st; }
 };
@@ -848,6 +889,11 @@ template <> struct enc_tab<true> {
         double Md, u8* __restrict__ out) const
     {
         enc_update_d(L, x, e, active, ql, Md, out);
+    }
+    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent_d& e, u32 ql, u32, double Md,
+        __amdgpu_buffer_rsrc_t rsrc, u32 obase, u8* __restrict__) const
+    {
+        enc_update_nb(L, x, e, ql, Md, rsrc, obase);
     }
     __device__ __forceinline__ void init(enc_lane& L, u64 Lb) const { L.sd = (double)Lb; }
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return f64_to_u64_exact(L.sd); }
@@ -889,6 +935,11 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     if constexpr (LDS_TABLE) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
     else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
+    // buffer view of the wave's 16 scratch slots (the host guarantees 16 * scr_stride < 2^31 for
+    // the LDS variant): wave-uniform descriptor, per-lane 32-bit offsets
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        scratch + (u64)(blockIdx.x * 16) * scr_stride, 0, (int)(16 * scr_stride), 0x00020000);
+    const u32 obase = (u32)((threadIdx.x >> 2) * scr_stride);
     const ansx_map f = g.map;  // value -> symbol map
     const u32 logM = B->logM;
     const u64 Lb = (u64)16 << logM;
@@ -961,12 +1012,12 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                 if (ck_per_batch) {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++)
-                        tab.step(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, Md, out);
+                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], ql, logM, Md, rsrc, obase, out);
                     record(sbtop - ANSX_ENC_U);
                 } else {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++) {
-                        tab.step(L, xa[sb * ANSX_ENC_U + j], e0[j], true, ql, logM, Md, out);
+                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], ql, logM, Md, rsrc, obase, out);
                         record(sbtop - 1 - j);
                     }
                 }

@@ -797,40 +797,70 @@ __device__ __forceinline__ void enc_update_d(enc_lane& L, u32 x, const enc_ent_d
     L.p += total;
 }
 
-// Branch-free form of the same step for the pipelined main loop.  hipcc keeps an
-// s_and_saveexec / s_cbranch_execz / s_or_b64 region around every predicated global store (VMEM
-// is never if-converted), i.e. 4 branches and 8 tiny basic blocks per step; a lone wave per SIMD
-// pays each branch as an issue bubble and the scheduler cannot move the independent table /
-// fold work of later steps into the stalls of the state chain.  Raw buffer stores make the
-// predicate part of the ADDRESS instead: a lane with nothing to write gets offset 2^31, beyond
-// num_records, and the hardware drops the access.  3 stores per step: the low two exception
-// bytes (k >= 2), the top exception byte (k odd), the renormalisation word.
+// Branch-free form of the same step for the pipelined main loop (LDS-table variant).
+//
+// Stores.  hipcc keeps an s_and_saveexec / s_cbranch_execz / s_or_b64 region around every
+// predicated global store (VMEM is never if-converted): 4 branches and 8 tiny basic blocks per
+// step, each an issue bubble for a lone wave and a barrier for the scheduler.  Raw buffer stores
+// make the predicate part of the ADDRESS instead: a lane with nothing to write gets offset 2^31,
+// beyond num_records, and the hardware drops the access.  Three stores per step, none of which
+// needs its value masked: byte 0 of x at a (k odd), 16 bits of x >> 8(k&1) at a + (k&1)
+// (k >= 2), the renormalisation word at a + k.
+//
+// Divide.  rcp is a deliberate UNDER-estimate of 1/F (relative deficit in (2^-39.01, 2^-38), see
+// enc_tab<true>::getp), so q' = trunc(s0 * rcp) is q or q-1, never above: one comparison
+// r' = s0 - q'F >= F decides the correction.  The update needs no corrected remainder:
+// q*M + (s0 - q*F) + base = q*(M - F) + (s0 + base), all integers below 2^53, so one fma is exact.
+//
+// Byte cursor.  Each lane puts its byte count c <= 7 into byte `ql` of a word; two DPP adds give
+// every lane the quad's packed counts S, and v_sad_u8 (sum of the four bytes of a word, plus an
+// accumulator) turns S & lomask into the lane's address and S into the next cursor.
 #define ANSX_BUF_OOB 0x80000000u
-__device__ __forceinline__ void enc_update_nb(enc_lane& L, u32 x, const enc_ent_d e, u32 ql, double Md,
-    __amdgpu_buffer_rsrc_t rsrc, u32 obase)
+struct enc_ent_n {
+    double Fd, rcp, thr, MF, based;
+    u32 k, kpos;
+};
+struct enc_quad_const {
+    u32 four_pos;  // 4 << (8 * ql)
+    u32 lomask;    // (1 << (8 * ql)) - 1
+};
+
+template <int P0, int P1, int P2, int P3> __device__ __forceinline__ u32 quad_add_perm(u32 v)
+{
+    // r = v[quad_perm] + v in one VOP2-DPP; s_nop 1 = the 2 wait states a DPP read needs after a
+    // VALU write of the same VGPR
+    u32 r;
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf"
+                 : "=v"(r)
+                 : "v"(v), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
+    return r;
+}
+
+__device__ __forceinline__ double f64_from_hi(u32 hi) { return __builtin_bit_cast(double, (u64)hi << 32); }
+
+__device__ __forceinline__ void enc_update_n(enc_lane& L, u32 x, const enc_ent_n e, const enc_quad_const qc,
+    __amdgpu_buffer_rsrc_t rsrc)
 {
     const u32 k = e.k;
-    const u32 eb = x & ((1u << (8 * k)) - 1u);
     const double sd = L.sd;
     const bool rn = sd >= e.thr;
-    const double hi = __builtin_trunc(sd * (1.0 / 4294967296.0));
-    const double wd = __builtin_fma(-hi, 4294967296.0, sd);
-    const u32 w = (u32)wd;
-    const double s0 = rn ? hi : sd;
+    // renormalise: s0 = rn ? state >> 32 : state;  w = low 32 bits (only stored when rn)
+    const double s0 = __builtin_trunc(sd * f64_from_hi(rn ? 0x3DF00000u : 0x3FF00000u));
+    const u32 w = (u32)__builtin_fma(-s0, 4294967296.0, sd);
     double qd = __builtin_trunc(s0 * e.rcp);
-    double rd = __builtin_fma(-qd, e.Fd, s0);
-    const double adj = (rd < 0.0) ? -1.0 : ((rd >= e.Fd) ? 1.0 : 0.0);
-    qd = qd + adj;
-    rd = __builtin_fma(-adj, e.Fd, rd);
-    L.sd = __builtin_fma(qd, Md, rd + e.based);
-    const u32 c = k + (rn ? 4u : 0u);
-    u32 total;
-    const u32 incl = quad_incl_scan(c, ql, &total);
-    const u32 a = obase + L.p + (incl - c);
-    __builtin_amdgcn_raw_buffer_store_b16((u16)eb, rsrc, (k >= 2) ? a : ANSX_BUF_OOB, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b8((u8)(eb >> (8 * (k - 1) & 31)), rsrc, (k & 1) ? a + k - 1 : ANSX_BUF_OOB, 0, 0);
+    const double rd = __builtin_fma(-qd, e.Fd, s0);
+    qd = qd + f64_from_hi((rd >= e.Fd) ? 0x3FF00000u : 0u);
+    L.sd = __builtin_fma(qd, e.MF, s0 + e.based);
+    // byte cursor (L.p carries the lane's buffer offset bias inside the pipelined loop)
+    const u32 v = e.kpos + (rn ? qc.four_pos : 0u);
+    const u32 s1 = quad_add_perm<1, 0, 3, 2>(v);
+    const u32 S = quad_add_perm<2, 3, 0, 1>(s1);
+    const u32 a = __builtin_amdgcn_sad_u8(S & qc.lomask, 0u, L.p);
+    L.p = __builtin_amdgcn_sad_u8(S, 0u, L.p);
+    const u32 t = k & 1u;
+    __builtin_amdgcn_raw_buffer_store_b8((u8)x, rsrc, t ? a : ANSX_BUF_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b16((u16)(x >> (t << 3)), rsrc, (k >= 2) ? a + t : ANSX_BUF_OOB, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, rn ? a + k : ANSX_BUF_OOB, 0, 0);
-    L.p += total;
 }
 
 __device__ __forceinline__ u64 f64_to_u64_exact(double d)  // d is an integer in [0, 2^53)
@@ -860,8 +890,10 @@ template <> struct enc_tab<false> {
     {
         enc_update(L, x, e, active, ql, logM, out);
     }
-    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent& e, u32 ql, u32 logM, double,
-        __amdgpu_buffer_rsrc_t, u32, u8* __restrict__ out) const
+    typedef enc_ent entp;
+    __device__ __forceinline__ enc_ent getp(const ansx_map& mp, u32 x, double, u32) const { return get(mp, x); }
+    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent& e, const enc_quad_const&, u32 ql,
+        u32 logM, __amdgpu_buffer_rsrc_t, u8* __restrict__ out) const
     {
         enc_update(L, x, e, true, ql, logM, out);
     }
@@ -890,10 +922,30 @@ template <> struct enc_tab<true> {
     {
         enc_update_d(L, x, e, active, ql, Md, out);
     }
-    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent_d& e, u32 ql, u32, double Md,
-        __amdgpu_buffer_rsrc_t rsrc, u32 obase, u8* __restrict__) const
+    typedef enc_ent_n entp;
+    __device__ __forceinline__ enc_ent_n getp(const ansx_map& mp, u32 x, double Md, u32 ql8) const
     {
-        enc_update_nb(L, x, e, ql, Md, rsrc, obase);
+        enc_ent_n r;
+        r.k = map_nbytes(mp, x);
+        const u32 e = t[map_sym(mp, x, r.k)];
+        r.Fd = (double)(e & 0xFFFFu);
+        r.based = (double)(e >> 16);
+        // 1/F, under-estimated on purpose: hardware seed r0 (relative error <= 2^-24.5, measured)
+        // and one Newton step against 1 - 2^-39 instead of 1:
+        //   r1 = r0 + r0 * (1 - 2^-39 - F*r0) = (1/F) * (1 - d0^2 - 2^-39 (1 + d0)),  d0^2 <= 2^-49
+        // so the relative deficit lies in (2^-39.01, 2^-38): s0 * r1 < s0 / F always, and by less
+        // than 2^36 * 2^-38 = 1/4 (+ 2^-17 of rounding), i.e. trunc() is q or q - 1.
+        const double r0 = __builtin_amdgcn_rcp(r.Fd);
+        r.rcp = __builtin_fma(__builtin_fma(-r.Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
+        r.thr = r.Fd * 68719476736.0;  // 2^36 * freq = K * RADIX * freq (ans_fold.hpp:89)
+        r.MF = Md - r.Fd;
+        r.kpos = r.k << ql8;
+        return r;
+    }
+    __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent_n& e, const enc_quad_const& qc,
+        u32, u32, __amdgpu_buffer_rsrc_t rsrc, u8* __restrict__) const
+    {
+        enc_update_n(L, x, e, qc, rsrc);
     }
     __device__ __forceinline__ void init(enc_lane& L, u64 Lb) const { L.sd = (double)Lb; }
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return f64_to_u64_exact(L.sd); }
@@ -958,13 +1010,14 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     const u32 cg = g.ckpt >> 2;  // groups per restart interval (0 = none)
     u32 ck_seg = (cg && G) ? (G - 1) / cg : 0;  // next restart point to record: segment index
     u32 ck_g = ck_seg * cg;                     // ... and its group index
+    u32 pbias = 0;  // inside the pipelined loop of the LDS variant L.p is a buffer offset (+ obase)
     auto record = [&](u32 gidx) {
         // every symbol with index >= 4*gidx is now encoded: decoder restart point of segment
         // ck_seg (the decoder of that segment starts with exactly these states and cursor)
         if (ck_seg && gidx == ck_g) {
             const u64 idx = (u64)b * g.nckf + (ck_seg - 1);
             ckpt_state[idx * 4 + ql] = tab.state(L);
-            if (ql == 0) ckpt_off[idx] = L.p;
+            if (ql == 0) ckpt_off[idx] = L.p - pbias;
             ck_seg--;
             ck_g -= cg;
         }
@@ -987,45 +1040,74 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         // restart points fall on sub-batch boundaries when the interval is a multiple of U groups
         const bool ck_per_batch = (cg % ANSX_ENC_U) == 0;
         const u32* base = src + 3 - ql;
+        const enc_quad_const qc = { 4u << (8 * ql), (1u << (8 * ql)) - 1u };
+        if constexpr (LDS_TABLE) {
+            pbias = obase;
+            L.p += obase;
+        }
         u32 xa[ANSX_ENC_XB], xb[ANSX_ENC_XB];
 #pragma unroll
         for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = base[4 * (gi - 1 - j)];
         while (gi) {
             const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
             if (top >= 2 * ANSX_ENC_XB) {
+                // Issued as inline asm so that hipcc's waitcnt pass does not see these loads: it
+                // would put s_waitcnt vmcnt(31..0) in front of their first use, and because vmcnt
+                // is in-order and shared with stores that is a full drain of the 96 stores of this
+                // super-batch (measured: 30 % of the wave's cycles in s_waitcnt).  The loads are
+                // consumed a whole super-batch later, behind those 96 stores; vmcnt is a 6-bit
+                // counter, so anything older than 63 operations has completed — enc_xb_ready()
+                // below states that explicitly with a wait that never touches recent stores.
 #pragma unroll
-                for (int j = 0; j < ANSX_ENC_XB; j++) xb[j] = base[4 * (top - ANSX_ENC_XB - 1 - j)];
+                for (int j = 0; j < ANSX_ENC_XB; j++)
+                    asm volatile("global_load_dword %0, %1, off"
+                                 : "=v"(xb[j])
+                                 : "v"(base + 4 * (top - ANSX_ENC_XB - 1 - j))
+                                 : "memory");
             }
-            typename enc_tab<LDS_TABLE>::ent e1[ANSX_ENC_U];
+            typename enc_tab<LDS_TABLE>::entp e1[ANSX_ENC_U];
 #pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, xa[j]);
+            for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.getp(f, xa[j], Md, 8 * ql);
 #pragma unroll
             for (int sb = 0; sb < ANSX_ENC_XB / ANSX_ENC_U; sb++) {
-                typename enc_tab<LDS_TABLE>::ent e0[ANSX_ENC_U];
+                typename enc_tab<LDS_TABLE>::entp e0[ANSX_ENC_U];
 #pragma unroll
                 for (int j = 0; j < ANSX_ENC_U; j++) e0[j] = e1[j];
                 if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
 #pragma unroll
-                    for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.get(f, xa[(sb + 1) * ANSX_ENC_U + j]);
+                    for (int j = 0; j < ANSX_ENC_U; j++)
+                        e1[j] = tab.getp(f, xa[(sb + 1) * ANSX_ENC_U + j], Md, 8 * ql);
                 }
                 const u32 sbtop = top - sb * ANSX_ENC_U;  // groups sbtop-1 ... sbtop-U
                 if (ck_per_batch) {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++)
-                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], ql, logM, Md, rsrc, obase, out);
+                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], qc, ql, logM, rsrc, out);
                     record(sbtop - ANSX_ENC_U);
                 } else {
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++) {
-                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], ql, logM, Md, rsrc, obase, out);
+                        tab.step_nb(L, xa[sb * ANSX_ENC_U + j], e0[j], qc, ql, logM, rsrc, out);
                         record(sbtop - 1 - j);
                     }
                 }
             }
             gi = top - ANSX_ENC_XB;
+            // >= 96 buffer stores were issued after the xb loads: waiting until at most 40 VMEM
+            // operations are outstanding proves the loads done (in-order counter) and only
+            // involves stores that are >= 13 steps old.  The "+v" operands keep every use of xb
+            // behind the wait.
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_XB; j += 8)
+                asm volatile(""
+                             : "+v"(xb[j]), "+v"(xb[j + 1]), "+v"(xb[j + 2]), "+v"(xb[j + 3]), "+v"(xb[j + 4]),
+                             "+v"(xb[j + 5]), "+v"(xb[j + 6]), "+v"(xb[j + 7]));
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = xb[j];
         }
+        L.p -= pbias;
+        pbias = 0;
     }
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
     st_u64_unaligned(out + L.p + 8 * ql, tab.state(L) - Lb);

@@ -376,8 +376,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
     const size_t LDS_LIMIT = 150 * 1024;
     // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
-    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + rup((size_t)max_ns * 4, 16)
-        + rup((size_t)max_ns * 2, 16) + mfb;
+    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16);
     if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !getenv("ANSX_DECODE_TABLE")) {
         size_t lds = rs_tables;
         u32 stream_cap = 0;

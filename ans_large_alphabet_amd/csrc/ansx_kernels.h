@@ -1348,72 +1348,96 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
 //                 compact per-present-symbol entries (base << 16 | freq) and symbol ids.  Still
 //                 two dependent LDS reads per step, but 6 instead of 4 workgroups fit a CU and
 //                 frames up to 2^16 keep their tables (and the staged stream) in LDS.
+// Both return freq, base and pv = k << 30 | value-without-exception-bytes for the slot's symbol
+// (k = number of exception bytes, ans_fold.hpp:150-175; for ANSrfold with the reorder flag set the
+// value is the remapped one, ans_reorder_fold.hpp:207-219,300-301 -- with flag 0 plain fold,
+// SURVEY F3).
+#define ANSX_PV_MASK 0x3FFFFFFFu
+// mfv: the block's most-frequent-table entry of sym (only read when rf && sym < T)
+__device__ __forceinline__ u32 dec_make_pv(const ansx_map& f, u32 sym, bool rf, u32 T, u32 mfv)
+{
+    const u32 k = unmap_nbytes(f, sym);
+    u32 v0 = unmap_value(f, sym, k);
+    if (rf) v0 = (sym < T) ? mfv : (v0 - T);
+    return (k << 30) | (v0 & ANSX_PV_MASK);
+}
 struct dec_lut_table {
     const u32* cum;
     const u16* s2s;
-    __device__ __forceinline__ void get(u32 slot, u32& sym, u32& fr, u32& base) const
+    ansx_map f;
+    u32 T;
+    const u32* mf;  // non-null: ANSrfold block with the reorder flag set
+    __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
     {
-        sym = s2s[slot];
+        const u32 sym = s2s[slot];
         const u32 c0 = cum[sym], c1 = cum[sym + 1];
         fr = c1 - c0;
         base = c0;
+        pv = dec_make_pv(f, sym, mf != nullptr, T, (mf != nullptr && sym < T) ? mf[sym] : 0u);
     }
 };
 struct dec_lut_rank {
     const uint2* bwp;  // {bitmap word, set bits before it}
     const u32* ent;    // per present symbol: base << 16 | freq
-    const u16* psym;   // per present symbol: symbol id
-    __device__ __forceinline__ void get(u32 slot, u32& sym, u32& fr, u32& base) const
+    const u32* pval;   // per present symbol: k << 30 | value without its exception bytes
+    __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
     {
         const uint2 wp = bwp[slot >> 5];
-        const u32 m = wp.x & (0xFFFFFFFFu >> (31u - (slot & 31u)));
-        const u32 r = (u32)__builtin_popcount(m) + wp.y - 1u;
+        // bits [0, slot & 31] of the word: shift the rest out at the top (the shifter uses the low
+        // five bits of ~slot = 31 - (slot & 31))
+        const u32 r = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y - 1u;
         const u32 e = ent[r];
-        sym = psym[r];
+        pv = pval[r];
         fr = e & 0xFFFFu;
         base = e >> 16;
     }
 };
 
-template <bool RFOLD, bool STREAM_LDS, typename LUT>
-__device__ __forceinline__ u32 dec_step(u64& st, int& p, bool active, u32 ql, const ansx_map& f, u32 rfT,
-    u32 logM, u32 mask, u64 Lb, const LUT& lut, const u32* mf, u32 rflag, const u8* __restrict__ stream,
-    const u32* lds_stream)
+// One decoder step of one state (ans_fold.hpp:216-228,135-147).  q = -(byte cursor): the bytes a
+// quad consumes in a step (per lane: renorm word, exception bytes below it) are located by the
+// packed-byte quad sum of enc_update_n: lane ql puts its count into byte ql, two DPP adds give
+// every lane the quad's counts S, v_sad_u8 adds the bytes of S & lomask (lanes before this one) or
+// of S (all four) onto q.
+struct dec_quad_const {
+    u32 ql8;     // 8 * ql
+    u32 lomask;  // (1 << 8 ql) - 1
+};
+template <bool STREAM_LDS, typename LUT>
+__device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_quad_const qc, u32 logM, u32 mask,
+    u64 Lb, const LUT& lut, const u8* __restrict__ stream, const u32* lds_stream)
 {
     const u32 slot = (u32)st & mask;
-    u32 sym, fr, base;
-    lut.get(slot, sym, fr, base);
+    u32 fr, base, pv;
+    lut.get(slot, fr, base, pv);
     u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - base);  // ans_fold.hpp:218-220
     const bool rn = active && (ns_ < Lb);
-    const u32 k = unmap_nbytes(f, sym);
+    const u32 k = pv >> 30;
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
-    u32 total;
-    const u32 incl = quad_incl_scan(c, ql, &total);
-    int myp = p - (int)(incl - c);
+    const u32 s1 = quad_add_perm<1, 0, 3, 2>(c << qc.ql8);
+    const u32 S = quad_add_perm<2, 3, 0, 1>(s1);
+    int myp = -(int)__builtin_amdgcn_sad_u8(S & qc.lomask, 0u, q);
+    q = __builtin_amdgcn_sad_u8(S, 0u, q);
     myp = myp < 0 ? 0 : myp;
     const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp);
-    if (rn) ns_ = (ns_ << 32) | (v >> 32);  // ans_fold.hpp:221-225
+    const u32 hi = (u32)(v >> 32), lo = (u32)v;
+    if (rn) ns_ = (ns_ << 32) | hi;  // ans_fold.hpp:221-225
     if (active) st = ns_;
-    // exception bytes sit just below the renorm word (ans_fold.hpp:135-147)
-    const u32 e = c ? ((u32)(v >> (64 - 8 * c)) & ((1u << (8 * k)) - 1u)) : 0u;
-    u32 val = unmap_value(f, sym, k) + e;
-    if (RFOLD) {
-        const u32 T = rfT;
-        if (rflag) val = (sym < T) ? mf[sym] : (val - T);  // ans_reorder_fold.hpp:207-219,300-301
-    }
-    p -= (int)total;
-    return val;
+    // the k exception bytes sit just below the renorm word (or at the top when there is none):
+    // the top k bytes of lo resp. hi; v_bfe with width 0 yields 0 for k = 0
+    const u32 k8 = k << 3;
+    const u32 e = __builtin_amdgcn_ubfe(rn ? lo : hi, 32u - k8, k8);
+    return (pv & ANSX_PV_MASK) + e;
 }
 
 // decode every segment of one block (one quad of lanes per segment)
-template <bool RFOLD, bool STREAM_LDS, typename LUT>
+template <bool STREAM_LDS, typename LUT>
 __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u32 sbytes, u32 tid,
-    u32 nt, const ansx_map& f, u32 rfT, u32 logM, const LUT& lut, const u32* mfl, u32 rflag,
-    const u8* __restrict__ stream, const u32* lds_stream, const u64* __restrict__ ckpt_state,
-    const u32* __restrict__ ckpt_off, u32* __restrict__ o)
+    u32 nt, u32 logM, const LUT& lut, const u8* __restrict__ stream, const u32* lds_stream,
+    const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o)
 {
     const u32 nseg = geo_nseg(nb, g.ckpt);
     const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
+    const dec_quad_const qc = { 8 * ql, (1u << (8 * ql)) - 1u };
     const u64 Lb = (u64)16 << logM;
     const u32 mask = (1u << logM) - 1;
     const u32 rtail = nb & 3, nfull = nb - rtail;
@@ -1429,13 +1453,28 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
             u32 po = ckpt_off[idx];
             p = (int)(po < sbytes ? po : sbytes);
         }
+        u32 q = (u32)(-p);
         const u32 start = seg * g.ckpt;
         u32 end = (seg == nseg - 1) ? nfull : (start + g.ckpt);
         end = end < nfull ? end : nfull;
         if (STREAM_LDS) {
-            for (u32 i = start; i < end; i += 4) {
-                u32 val = dec_step<RFOLD, true>(st, p, true, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
-                o[i + ql] = val;
+            u32* op = o + start + ql;
+            const u32 steps = (end - start) >> 2;
+            const u32 steps0 = (u32)__builtin_amdgcn_readfirstlane((int)steps);
+            if (__builtin_amdgcn_ballot_w64(steps != steps0) == 0) {
+                // every quad of the wave decodes the same number of groups (all but the wave that
+                // holds a short last segment): scalar trip count, unrolled
+                u32 i = 0;
+                for (; i + 4 <= steps0; i += 4) {
+#pragma unroll
+                    for (u32 u = 0; u < 4; u++)
+                        op[4 * (i + u)] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                }
+                for (; i < steps0; i++)
+                    op[4 * i] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+            } else {
+                for (u32 i = 0; i < steps; i++)
+                    op[4 * i] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
             }
         } else {
             // The cursor walks down the stream ~4.5 bytes per step; pull the next 512 bytes
@@ -1444,21 +1483,20 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
             int pf_front = p;
             u32 pf = 0;
             for (u32 i = start; i < end; i += 4) {
-                if (p - 256 < pf_front) {
+                if (-(int)q - 256 < pf_front) {
                     asm volatile("" ::"v"(pf));
                     int a = pf_front - 128 * (int)(ql + 1);
                     a = a < 0 ? 0 : a;
                     pf = ld_u32_unaligned(stream + (a & ~3));
                     pf_front -= 512;
                 }
-                u32 val = dec_step<RFOLD, false>(st, p, true, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
-                o[i + ql] = val;
+                o[i + ql] = dec_step<false>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
             }
             asm volatile("" ::"v"(pf));
         }
         if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
             for (u32 i = nfull; i < nb; i++) {
-                u32 val = dec_step<RFOLD, STREAM_LDS>(st, p, ql == 3, ql, f, rfT, logM, mask, Lb, lut, mfl, rflag, stream, lds_stream);
+                u32 val = dec_step<STREAM_LDS>(st, q, ql == 3, qc, logM, mask, Lb, lut, stream, lds_stream);
                 if (ql == 3) o[i] = val;
             }
         }
@@ -1510,20 +1548,12 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     off += (wmax * 8 + 15) & ~15u;
     u32* ent = (u32*)(smem + off);
     off += (max_ns * 4 + 15) & ~15u;
-    u16* psym = (u16*)(smem + off);
-    off += (max_ns * 2 + 15) & ~15u;
-    u32* mfl = nullptr;
-    if (RFOLD) {
-        mfl = (u32*)(smem + off);
-        off += 4 * T;
-    }
+    u32* pval = (u32*)(smem + off);
+    off += (max_ns * 4 + 15) & ~15u;
     u32* lds_stream = (u32*)(smem + off);
     const u32 W = M >= 32 ? M / 32 : 1;
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
     if (tid == 0) sh_bad = 0;
-    if (RFOLD && rflag) {
-        for (u32 i = tid; i < T; i += nt) mfl[i] = ld_u32_unaligned(stream + 4 + 4 * (u64)i);
-    }
     const bool st_lds = (sbytes + 24 <= stream_cap);
     if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
     __syncthreads();
@@ -1559,7 +1589,11 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
                 if (base < M && base + fr <= M) {
                     const u32 r = carryP + incP - 1;
                     ent[r] = (base << 16) | fr;
-                    psym[r] = (u16)s;
+                    // ANSrfold: the most-frequent values follow the 4-byte flag word
+                    // (ans_reorder_fold.hpp:132-154)
+                    u32 mfv = 0;
+                    if (RFOLD && rflag && s < T) mfv = ld_u32_unaligned(stream + 4 + 4 * (u64)s);
+                    pval[r] = dec_make_pv(f, s, RFOLD && rflag, T, mfv);
                     atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
                 } else {
                     bad = 1;
@@ -1601,12 +1635,12 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     dec_lut_rank lut;
     lut.bwp = bwp;
     lut.ent = ent;
-    lut.psym = psym;
+    lut.pval = pval;
     u32* o = outp + (u64)b * g.block_ints;
     if (st_lds)
-        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
-        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<false>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
 }
 
 // k_decode: slot -> symbol table form, any frame size; tables in LDS (LDS_TAB) or in HBM.
@@ -1705,9 +1739,12 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     dec_lut_table lut;
     lut.cum = cum;
     lut.s2s = s2s;
+    lut.f = f;
+    lut.T = T;
+    lut.mf = (RFOLD && rflag) ? mfl : nullptr;
     u32* o = outp + (u64)b * g.block_ints;
     if (st_lds)
-        dec_segments<RFOLD, true>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
-        dec_segments<RFOLD, false>(g, b, nb, sbytes, tid, nt, f, T, logM, lut, mfl, rflag, stream, lds_stream, ckpt_state, ckpt_off, o);
+        dec_segments<false>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
 }

@@ -43,7 +43,7 @@ struct ansx_ctx {
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp;
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
 };
 
@@ -241,6 +241,10 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if ((rc = ensure(c, c->attS, (size_t)NB * ANSX_ATTEMPTS * NSP * 2))) return rc;
     if ((rc = ensure(c, c->prevS, (size_t)NB * NSP * 2))) return rc;
     if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 16))) return rc;
+    if (!c->log2lut.p) {  // stage-1 table of the portable log2, once per context (1.5 MB)
+        if ((rc = ensure(c, c->log2lut, (size_t)65536 * sizeof(ansx_log2_ent)))) return rc;
+        LAUNCH(c, "k_build_log2_lut", k_build_log2_lut, 256, 256, 0, s, (ansx_log2_ent*)c->log2lut.p);
+    }
     if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
     if ((rc = ensure(c, c->table, (size_t)NB * NSP * sizeof(ansx_enc_entry)))) return rc;
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
@@ -278,13 +282,16 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     // blocks that fit one histogram workgroup (the normal case) get their entropy terms from K1
     // and the in-order sum from K2b; longer blocks keep both in K2a
     const bool h_deferred = (cpb == 1);
+    // entropy terms are evaluated by the histogram kernel when it sees whole blocks; alphabets up
+    // to 2048 slots are also summed there (terms in LDS), larger ones through HBM in K2b
+    const bool h_in_hist = h_deferred && NSP <= 2048;
     double* hterm = nullptr;
-    if (h_deferred) {
+    if (h_deferred && !h_in_hist) {
         if ((rc = ensure(c, c->hterm, (size_t)NB * NSP * 8))) return rc;
         hterm = (double*)c->hterm.p;
     }
-    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * 4, s, src, g, chunk, cpb, NSP,
-        hist, hterm, blk, gflags, 1u << 30);
+    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * (h_in_hist ? 12 : 4) + (h_in_hist ? 80 : 0), s, src, g, chunk, cpb,
+        NSP, hist, hterm, h_in_hist ? 1u : 0u, blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4;
@@ -305,7 +312,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
             0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
-            (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)hterm);
+            (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)hterm, (const ansx_log2_ent*)c->log2lut.p);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
             (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);
@@ -609,7 +616,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {

@@ -87,7 +87,11 @@ ANSX_HD u64 ansx_f64_to_bits(double d)
 }
 
 #pragma clang fp contract(off)
-ANSX_HD double ansx_log2_portable(double x)
+// Stage 1: everything that depends on the mantissa of x only (plus the exponent it starts from);
+// stage 2: the final e + y.  log2(x * 2^-k) = stage2(e - k, y, ylo) bit for bit, because scaling
+// by a power of two changes nothing but the exponent field -- the normaliser uses this for
+// q = S / M with integer S <= 65535 and M = 2^k (util.hpp:284-298), reading stage 1 from a table.
+ANSX_HD void ansx_log2_stage1(double x, int* e_out, double* y_out, double* ylo_out)
 {
     // x is a ratio of positive integers < 2^53: positive, finite, normal.
     u64 ix = ansx_f64_to_bits(x);
@@ -132,11 +136,24 @@ ANSX_HD double ansx_log2_portable(double x)
     double y = t * IL2_HI;
     double ye = __builtin_fma(t, IL2_HI, -y);
     double ylo = __builtin_fma(tlo, IL2_HI, __builtin_fma(t, IL2_LO, ye));
+    *e_out = e;
+    *y_out = y;
+    *ylo_out = ylo;
+}
+ANSX_HD double ansx_log2_stage2(int e, double y, double ylo)
+{
     // e + y with Fast2Sum (e == 0 or |e| >= 1 > |y|)
     double ed = (double)e;
     double hi = ed + y;
     double herr = y - (hi - ed);
     return hi + (herr + ylo);
+}
+ANSX_HD double ansx_log2_portable(double x)
+{
+    int e;
+    double y, ylo;
+    ansx_log2_stage1(x, &e, &y, &ylo);
+    return ansx_log2_stage2(e, y, ylo);
 }
 
 // ---------------------------------------------------------------------------------------------

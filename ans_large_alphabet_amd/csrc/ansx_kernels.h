@@ -49,7 +49,7 @@ enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 // loads.  Replaces the first pass of ans_fold_encode<f>::create (ans_fold.hpp:74-78).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
-    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm,
+    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm, u32 sum_here,
     ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
 {
     extern __shared__ u32 lds_hist[];
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     const u32 len = (u32)((nb - start) < chunk ? (nb - start) : chunk);
     const u32* src = in + (u64)b * g.block_ints + start;
     for (u32 s = tid; s < NSP; s += 256) lds_hist[s] = 0;
+    if (sum_here && tid < 17) lds_hist[3 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
     __syncthreads();
     const ansx_map mp = g.map;
     u32 lmax = 0, bad = 0;
@@ -88,11 +89,15 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     __syncthreads();
     u32* h = hist + (u64)b * NSP;
     if (cpb == 1) {
-        // the block's histogram is complete here: also emit the entropy terms p*log2(p)
-        // (util.hpp:276-279) for the in-order sum taken later by k_scale_attempts; an absent
-        // symbol contributes +0.0, which leaves that sum (never -0.0) unchanged
+        // the block's histogram is complete here: also evaluate the entropy terms p*log2(p)
+        // (util.hpp:276-279), 256 at a time; an absent symbol contributes +0.0, which leaves the
+        // in-order sum (never -0.0) unchanged.  Small alphabets (sum_here): the terms go to LDS
+        // and thread 0 adds them left to right, exactly like the scalar loop of util.hpp:271-282
+        // (~5 cycles per dependent add; the other workgroups of the CU keep streaming).  Large
+        // ones: the terms go to HBM and k_scale_attempts sums them.
         const double nd = (double)nb;
-        double* ht = hterm + (u64)b * NSP;
+        double* lds_term = (double*)(lds_hist + NSP);
+        double* ht = sum_here ? nullptr : hterm + (u64)b * NSP;
         for (u32 s = tid; s < NSP; s += 256) {
             const u32 fr = lds_hist[s];
             h[s] = fr;
@@ -101,7 +106,37 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
                 const double p = (double)fr / nd;
                 t = p * ansx_log2_portable(p);
             }
-            ht[s] = t;
+            if (sum_here) lds_term[s] = t;
+            else ht[s] = t;
+        }
+        if (sum_here) {
+            // symbols above the block's largest one are absent (+0.0 terms): stop there
+            u32 wmax = lmax;
+            for (int o = 32; o > 0; o >>= 1) {
+                const u32 t = __shfl_xor(wmax, o);
+                wmax = t > wmax ? t : wmax;
+            }
+            if ((tid & 63) == 0) atomicMax(&lds_hist[3 * NSP + 16], wmax);  // word after the padded terms
+            __syncthreads();
+            if (tid == 0) {
+                const u32 ns8 = (lds_hist[3 * NSP + 16] + 8u) & ~7u;  // <= NSP (a multiple of 8)
+                double acc = 0.0;
+                double t8[8], n8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = lds_term[u];
+                for (u32 i = 0; i < ns8; i += 8) {
+                    // next 8 terms in flight while these 8 are added (rows are NSP + 8 terms long)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) n8[u] = lds_term[i + 8 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc = acc + t8[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) t8[u] = n8[u];
+                }
+                const double H = -acc;
+                blk[b].H = H;
+                blk[b].thr = H * (1.0 + (double)1 / (double)1000);  // ans_util.hpp:124
+            }
         }
     } else {
         for (u32 s = tid; s < NSP; s += 256) {
@@ -283,12 +318,29 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         B->n = (u32)total;
         B->sigma = sigma;
         B->m0_log2 = m0;
-        B->H = H;
-        B->thr = H * approx;
+        if (!h_deferred) {  // otherwise k_fold_hist / k_scale_attempts own the entropy
+            B->H = H;
+            B->thr = H * approx;
+        }
         B->resolved = 0;
         B->prev = -1;
         B->status = 0;
     }
+}
+
+// Stage-1 results of ansx_log2_portable for x = 1 .. 65535 (entry 0 unused): one table per context.
+struct ansx_log2_ent {
+    double y, ylo;
+    int e, pad;
+};
+__global__ void k_build_log2_lut(ansx_log2_ent* __restrict__ lut)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 65536u) return;
+    ansx_log2_ent r;
+    r.pad = 0;
+    ansx_log2_stage1((double)(i ? i : 1u), &r.e, &r.y, &r.ylo);
+    lut[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -303,7 +355,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u32* __restrict__ sortF, const u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk, u16* __restrict__ attS, u32* __restrict__ attMeta,
-    const double* __restrict__ hterm)
+    const double* __restrict__ hterm, const ansx_log2_ent* __restrict__ l2lut)
 {
     const u32 gid = blockIdx.x * 256 + threadIdx.x;
     const u32 b = gid / ANSX_ATTEMPTS, t = gid % ANSX_ATTEMPTS;
@@ -391,7 +443,6 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     const double nd = (double)(int)B.n;
     // q = S / M with M = 2^sh: the division by a power of two is exact, so it is a multiply
     // (sh == 31 would make (int)M negative in util.hpp:289; such frames never reach this point)
-    const double inv_md = ansx_bits_to_f64((u64)(1023 - sh) << 52);
     double acc = 0.0;
     uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4);
     for (u32 i0 = 0; i0 < ns; i0 += 8) {
@@ -404,12 +455,18 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
             hb = *(const uint4*)(h + i0 + 12);
         }
         double tm[8];
+        // log2(q), q = S * 2^-sh with integer S <= 65535: the mantissa-dependent part of
+        // ansx_log2_portable comes from the per-context table (built by the same code, so the
+        // value is bit-identical to evaluating the function on q), the exponent part is e(S) - sh
+        ansx_log2_ent le[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) le[u] = l2lut[s8[u]];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
             const double p = valid ? (double)h8[u] / nd : 0.0;
-            const double q = valid ? (double)s8[u] * inv_md : 1.0;
-            tm[u] = p * ansx_log2_portable(q);
+            const double lg = ansx_log2_stage2(le[u].e - (int)sh, le[u].y, le[u].ylo);
+            tm[u] = p * (valid ? lg : 0.0);  // absent: p * log2(1) = +0.0
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) acc = acc + tm[u];

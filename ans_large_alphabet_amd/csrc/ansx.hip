@@ -294,7 +294,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         NSP, hist, hterm, h_in_hist ? 1u : 0u, blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
-    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4;
+    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4 + (h_deferred ? 0 : 512 * 8);
     if (k2a_lds > 32 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));

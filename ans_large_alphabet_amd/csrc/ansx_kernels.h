@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 // Entropy: p*log2(p) terms lane-parallel, summed serially in index order so that the rounding
 // matches a scalar left-to-right accumulation.
 // ------------------------------------------------------------------------------------------
-#define ANSX_VMAX 2048u
+#define ANSX_VMAX 512u
+#define ANSX_MASKV 512u
 
 // Single-wave workgroups: LDS operations of one wave execute in order, so a "barrier" only has
 // to stop the compiler from reordering and wait for the LDS queue; __syncthreads() would also
@@ -182,10 +183,11 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
     __shared__ u32 cnt[ANSX_VMAX];
     __shared__ u16 cnt0[ANSX_VMAX];  // number of symbols per frequency value (before the scan)
-    __shared__ double terms[512];
+    __shared__ unsigned long long vmask[ANSX_MASKV];  // lanes of the current pass per frequency value
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
-    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [ns] this block's histogram row
+    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [NSP] this block's histogram row
+    double* terms = (double*)(hrow + NSP);   // [512], only allocated when the entropy is summed here
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const u32 ns = blk[b].max_sym + 1;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     // stage the histogram row once (coalesced, all loads in flight together)
     for (u32 s = lane; s < ns; s += 64) hrow[s] = h[s];
     for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
+    for (u32 v = lane; v < ANSX_MASKV; v += 64) vmask[v] = 0;
     if (lane == 0) sh_nbig = 0;
     wave_lds_sync();
     // pass 1: bin the frequencies
@@ -254,12 +257,33 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             oF[pos] = fr;
             oS[pos] = (u16)s;
         }
-        unsigned long long todo = __ballot(small && !uniq);
+        // Rank among the lanes of this pass that share a frequency value.  Values below
+        // ANSX_MASKV (practically all that occur more than once): every lane ORs its lane bit
+        // into the value's 64-bit LDS mask, reads the mask back, and its rank is the number of
+        // set bits below it -- independent of the order in which the LDS unit applies the
+        // atomics; the lowest lane then advances the value's cursor and clears the mask.  (The
+        // LDS operations of one wave execute in program order.)
+        const bool masked = small && !uniq && fr < ANSX_MASKV;
+        if (masked) atomicOr(&vmask[fr], 1ull << lane);
+        wave_lds_sync();
+        if (masked) {
+            const unsigned long long m = vmask[fr];
+            const unsigned long long below = m & ((1ull << lane) - 1ull);
+            const u32 pos = cnt[fr] + (u32)__popcll(below);
+            oF[pos] = fr;
+            oS[pos] = (u16)s;
+            if (below == 0) {
+                cnt[fr] += (u32)__popcll(m);
+                vmask[fr] = 0;
+            }
+        }
+        // larger repeated values (rare): one ballot round per distinct value
+        unsigned long long todo = __ballot(small && !uniq && !masked);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const u32 v0 = (u32)__builtin_amdgcn_readlane((int)fr, leader);  // leader is wave-uniform
-            const unsigned long long m = __ballot(small && !uniq && fr == v0);
-            if (small && !uniq && fr == v0) {
+            const unsigned long long m = __ballot(small && !uniq && !masked && fr == v0);
+            if (small && !uniq && !masked && fr == v0) {
                 const u32 pos = cnt[v0] + (u32)__popcll(m & ((1ull << lane) - 1ull));
                 oF[pos] = fr;
                 oS[pos] = (u16)s;

@@ -290,7 +290,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         if ((rc = ensure(c, c->hterm, (size_t)NB * NSP * 8))) return rc;
         hterm = (double*)c->hterm.p;
     }
-    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, NSP * (h_in_hist ? 12 : 4) + (h_in_hist ? 80 : 0), s, src, g, chunk, cpb,
+    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, h_in_hist ? (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (size_t)NSP * 8 + 80 : (size_t)NSP * 4, s, src, g, chunk, cpb,
         NSP, hist, hterm, h_in_hist ? 1u : 0u, blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);

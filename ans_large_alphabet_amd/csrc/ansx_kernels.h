@@ -48,6 +48,7 @@ enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 // K1: folded-symbol histogram.  One workgroup per chunk of a block; LDS bins; coalesced 16 B
 // loads.  Replaces the first pass of ans_fold_encode<f>::create (ans_fold.hpp:74-78).
 // ------------------------------------------------------------------------------------------
+#define ANSX_HCOPY_PAD 8u
 __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
     u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm, u32 sum_here,
     ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
@@ -60,8 +61,16 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     if (start >= nb) return;
     const u32 len = (u32)((nb - start) < chunk ? (nb - start) : chunk);
     const u32* src = in + (u64)b * g.block_ints + start;
-    for (u32 s = tid; s < NSP; s += 256) lds_hist[s] = 0;
-    if (sum_here && tid < 17) lds_hist[3 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
+    // sum_here (alphabets <= 2048 slots): 4 histogram copies, lane l counts into copy l & 3.  With
+    // skewed data a dozen lanes of every ds_add hit the hottest bin and the LDS unit serialises
+    // them; copies are ANSX_HCOPY_PAD words apart modulo the 32 banks so the same symbol's four
+    // counters sit in different banks.  Layout: [4][NSP + pad] u32 | [NSP + 8] f64 terms | max word.
+    const u32 cstride = sum_here ? NSP + ANSX_HCOPY_PAD : 0;
+    const u32 hwords = sum_here ? 4 * cstride : NSP;
+    for (u32 s = tid; s < hwords; s += 256) lds_hist[s] = 0;
+    u32* const aux = lds_hist + hwords;  // terms (f64, 8-byte aligned: hwords is even), then the max word
+    if (sum_here && tid < 17) aux[2 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
+    u32* const my_hist = lds_hist + (tid & 3) * cstride;
     __syncthreads();
     const ansx_map mp = g.map;
     u32 lmax = 0, bad = 0;
@@ -69,14 +78,30 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         bad |= (x >= value_limit) ? 1u : 0u;
         u32 k = map_nbytes(mp, x);
         u32 s = map_sym(mp, x, k);
-        atomicAdd(&lds_hist[s], 1u);
+        atomicAdd(&my_hist[s], 1u);
         lmax = s > lmax ? s : lmax;
     };
     u32 done = 0;
     if ((((uintptr_t)src) & 15u) == 0) {
         const uint4* v4 = (const uint4*)src;
         const u32 nvec = len >> 2;
-        for (u32 v = tid; v < nvec; v += 256) {
+        // 8 independent 16-byte loads in flight per thread before any of them is consumed: the
+        // kernel is a latency chain otherwise (measured: 4 % VALU activity, 64 % of the wave's
+        // cycles in s_waitcnt with one load per iteration)
+        u32 v = tid;
+        for (; v + 7 * 256 < nvec; v += 8 * 256) {
+            uint4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = v4[v + j * 256];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                take(q[j].x);
+                take(q[j].y);
+                take(q[j].z);
+                take(q[j].w);
+            }
+        }
+        for (; v < nvec; v += 256) {
             uint4 q = v4[v];
             take(q.x);
             take(q.y);
@@ -96,10 +121,11 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         // (~5 cycles per dependent add; the other workgroups of the CU keep streaming).  Large
         // ones: the terms go to HBM and k_scale_attempts sums them.
         const double nd = (double)nb;
-        double* lds_term = (double*)(lds_hist + NSP);
+        double* lds_term = (double*)aux;
         double* ht = sum_here ? nullptr : hterm + (u64)b * NSP;
         for (u32 s = tid; s < NSP; s += 256) {
-            const u32 fr = lds_hist[s];
+            u32 fr = lds_hist[s];
+            if (sum_here) fr += lds_hist[cstride + s] + lds_hist[2 * cstride + s] + lds_hist[3 * cstride + s];
             h[s] = fr;
             double t = 0.0;
             if (fr) {
@@ -116,10 +142,10 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
                 const u32 t = __shfl_xor(wmax, o);
                 wmax = t > wmax ? t : wmax;
             }
-            if ((tid & 63) == 0) atomicMax(&lds_hist[3 * NSP + 16], wmax);  // word after the padded terms
+            if ((tid & 63) == 0) atomicMax(&aux[2 * NSP + 16], wmax);  // word after the padded terms
             __syncthreads();
             if (tid == 0) {
-                const u32 ns8 = (lds_hist[3 * NSP + 16] + 8u) & ~7u;  // <= NSP (a multiple of 8)
+                const u32 ns8 = (aux[2 * NSP + 16] + 8u) & ~7u;  // <= NSP (a multiple of 8)
                 double acc = 0.0;
                 double t8[8], n8[8];
 #pragma unroll

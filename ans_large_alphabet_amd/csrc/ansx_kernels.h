@@ -642,6 +642,36 @@ struct ansx_code {
     u32 code, len, rank;
 };
 
+// Exclusive prefix sum of one value per thread over a workgroup of NT threads (NT a multiple of
+// 64, <= 1024): wave scan over shuffles, wave totals through LDS.  *total = sum over the group.
+// wsum: NT/64 + 1 words of LDS scratch.  Contains two barriers.
+template <typename T> __device__ __forceinline__ T block_excl_scan(T v, T* wsum, u32 tid, u32 nt, T* total)
+{
+    T incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T t = __shfl_up(incl, d);
+        if ((int)(tid & 63) >= d) incl += t;
+    }
+    const u32 nw = nt >> 6;
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        const T w = tid < nw ? wsum[tid] : (T)0;
+        T wi = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {  // nw <= 16
+            const T t = __shfl_up(wi, d);
+            if ((int)tid >= d) wi += t;
+        }
+        if (tid < nw) wsum[tid] = wi - w;
+        if (tid == nw - 1) wsum[nw] = wi;
+    }
+    __syncthreads();
+    *total = wsum[nw];
+    return wsum[tid >> 6] + incl - v;
+}
+
 __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, u64 u, u32 i)
 {
     u32 a = 0, n = ns, rank = 0;
@@ -693,8 +723,7 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
 {
     extern __shared__ u32 lds32[];
-    __shared__ u32 sh_part[256];
-    __shared__ u32 sh_total;
+    __shared__ u32 sh_part[8];
     const u32 tid = threadIdx.x;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
@@ -727,25 +756,13 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const u32 lo = tid * per, hi = (lo + per) < ns ? (lo + per) : ns;
     u32 sum = 0;
     for (u32 s = lo; s < hi; s++) sum += off[s];
-    sh_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (u32 l = 0; l < 256; l++) {
-            u32 t = sh_part[l];
-            sh_part[l] = run;
-            run += t;
-        }
-        sh_total = run;
-    }
-    __syncthreads();
-    u32 run = sh_part[tid];
+    u32 total_bits;
+    u32 run = block_excl_scan<u32>(sum, sh_part, tid, 256, &total_bits);
     for (u32 s = lo; s < hi; s++) {
         u32 t = off[s];
         off[s] = run;
         run += t;
     }
-    const u32 total_bits = sh_total;
     const u32 nwords = (total_bits + 31) >> 5;
     for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
     __syncthreads();
@@ -1229,28 +1246,20 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(ansx_geo g, const ansx_blk*
     u64* __restrict__ block_off, u64* __restrict__ result, u64 payload_off, u64 capacity,
     u32* __restrict__ gflags)
 {
-    __shared__ u64 part[1024];
+    __shared__ u64 part[20];
     const u32 tid = threadIdx.x;
     const u32 NB = g.nblocks;
     const u32 per = (NB + 1023) / 1024;
     const u32 lo = tid * per, hi = (lo + per) < NB ? (lo + per) : NB;
     u64 sum = 0;
     for (u32 i = lo; i < hi; i++) sum += blk[i].stream_bytes;
-    part[tid] = sum;
-    __syncthreads();
+    u64 total;
+    u64 run = block_excl_scan<u64>(sum, part, tid, 1024, &total);
     if (tid == 0) {
-        u64 run = 0;
-        for (u32 l = 0; l < 1024; l++) {
-            u64 t = part[l];
-            part[l] = run;
-            run += t;
-        }
-        block_off[NB] = run;
-        result[0] = run;  // payload bytes
-        if (payload_off + run > capacity) atomicOr(&gflags[ANSX_G_ERR], 1u << 2 /* CAPACITY */);
+        block_off[NB] = total;
+        result[0] = total;  // payload bytes
+        if (payload_off + total > capacity) atomicOr(&gflags[ANSX_G_ERR], 1u << 2 /* CAPACITY */);
     }
-    __syncthreads();
-    u64 run = part[tid];
     for (u32 i = lo; i < hi; i++) {
         block_off[i] = run;
         run += blk[i].stream_bytes;

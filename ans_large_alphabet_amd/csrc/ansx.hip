@@ -372,9 +372,19 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     int rc;
     if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
     if ((rc = ensure(c, c->dec_info, (size_t)g.nblocks * 16))) return rc;
-    // K7: one lane per block, 64 blocks per wave
-    LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
-        boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    // K7: one lane per block, 64 blocks per wave.  Fast item loop when the interpolative values fit
+    // 16 bits and the per-lane arrays fit LDS (see k_parse_prelude_fast), generic loop otherwise.
+    const size_t pf_e = std::max<size_t>(20480, rup(((size_t)max_ns + 2) * 128, 16));
+    const size_t pf_lds = pf_e + (size_t)ANSX_PF_SW * 64 * 4 + 21 * 64 * 4;
+    if ((u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024 && !getenv("ANSX_PARSE_GENERIC")) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
+        LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    } else {
+        LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
+            boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    }
     // K8
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
     u32 threads = (u32)rup((size_t)nseg * 4, 64);

@@ -1328,16 +1328,17 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
 // lives in LDS with one 16-byte entry per pending right subtree.  Output per block: inc[] in
 // the global table row (cum[s+1] = inc[s], un-prefix-summed by k_decode) and
 // {nsyms, log2 M, rfold flag, error}.
+// Per-lane header of a block stream: ANSrfold flag + most-frequent table (ans_reorder_fold.hpp:
+// 238-254), vbyte(max_sym) (vbyte.hpp:82-95), log2 M (ans_util.hpp:27-31).
+struct parse_hdr {
+    u32 err, ns, logM, flag, pos, sbytes;
+    const u8* stream;
+};
 template <bool RFOLD>
-__global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
-    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+__device__ __forceinline__ parse_hdr parse_header(const u8* __restrict__ cont, const ansx_geo& g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, u32 b)
 {
-    __shared__ uint4 stk[20][64];  // [depth][lane]: conflict-free 16-byte accesses
-    const u32 lane = threadIdx.x;
     const u32 T = fold_T(g.f);
-    const u32 b = blockIdx.x * 64 + lane;
-    if (b >= g.nblocks) return;
     u32 err = 0, ns = 0, logM = 0, flag = 0;
     const u64 boff = block_off[b];
     const u8* stream = cont + payload_off + boff;
@@ -1362,7 +1363,20 @@ __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ con
     }
     ns = ms + 1;
     if (ns > max_ns || ns > NSP || logM > 30 || ((u64)1 << logM) > maxM || sbytes < pos + 32) err = 1;
-    if (!err) {
+    parse_hdr H;
+    H.err = err, H.ns = ns, H.logM = logM, H.flag = flag, H.pos = pos, H.sbytes = sbytes, H.stream = stream;
+    return H;
+}
+
+// Generic item loop (any alphabet / frame size): 128-bit register bit window refilled from global
+// memory one load ahead, traversal stack of (a, n, low, high) in LDS.  stk: [20][64] uint4.
+__device__ __forceinline__ u32 parse_items_generic(const parse_hdr& H, u32 NSP, u32 b, u32 lane,
+    uint4 (*stk)[64], u32* __restrict__ g_cum)
+{
+    u32 err = 0;
+    const u32 ns = H.ns, logM = H.logM, pos = H.pos, sbytes = H.sbytes;
+    const u8* stream = H.stream;
+    {
         const u8* bp = stream + pos;  // interpolative words start here
         u32* cum = g_cum + (u64)b * (NSP + 8);
         // 128-bit window: w0 = bits [base, base+64), w1 = next 64 bits (already in flight)
@@ -1432,7 +1446,125 @@ __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ con
             high = v - 1;
         }
     }
-    binfo[b] = make_uint4(ns, logM, flag, err);
+    return err;
+}
+
+template <bool RFOLD>
+__global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+{
+    __shared__ uint4 stk[20][64];  // [depth][lane]: conflict-free 16-byte accesses
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x * 64 + lane;
+    if (b >= g.nblocks) return;
+    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    u32 err = H.err;
+    if (!err) err = parse_items_generic(H, NSP, b, lane, stk, g_cum);
+    binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
+    if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+}
+
+// Fast item loop for the common shapes (frames + alphabets whose interpolative values fit 16 bits,
+// alphabets that fit LDS).  Three observations make the per-item chain short:
+//  * the traversal (which element is decoded when, interp.hpp:81-97) depends on ns only, so the
+//    next node is worked out while the current item's bits are being decoded, and its stack holds
+//    just (a, n);
+//  * a node's bounds are its neighbours' decoded values: low = E[a] + 1, high = E[a + n + 1] - 1
+//    with sentinels E[0] = 0, E[ns + 1] = u + 2; E lives in LDS as u16, [element][lane];
+//  * the first ANSX_PF_SW words of the prelude are staged in LDS, [word][lane]: an item reads its
+//    <= 31 bits through one 32-bit window (two words + v_alignbit), no refill logic, no 64-bit
+//    shifts, no loads behind the cum[] stores.
+// A lane whose prelude outgrows the staged words falls back to parse_items_generic afterwards.
+#define ANSX_PF_SW 128u
+template <bool RFOLD>
+__global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 pf_smem[];
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x * 64 + lane;
+    if (b >= g.nblocks) return;
+    u32 ebytes = (max_ns + 2) * 128;
+    ebytes = ebytes < 20480u ? 20480u : ((ebytes + 15u) & ~15u);  // also hosts the generic stack
+    u16* E = (u16*)pf_smem;                                         // [max_ns + 2][64]
+    u32* stage = (u32*)(pf_smem + ebytes);                          // [ANSX_PF_SW][64]
+    u32* stack = stage + ANSX_PF_SW * 64;                           // [21][64], row 20 = dump
+    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    u32 err = H.err, slow = 0;
+    if (!err) {
+        const u32 ns = H.ns;
+        const u8* bp = H.stream + H.pos;
+        const u32 avail = H.sbytes - H.pos;  // >= 32
+        const u32 nd = (avail >> 3) < ANSX_PF_SW / 2 ? (avail >> 3) : ANSX_PF_SW / 2;  // whole 8-byte pieces
+#pragma unroll 8
+        for (u32 j = 0; j < ANSX_PF_SW / 2; j++) {
+            const u64 v = j < nd ? ld_u64_unaligned(bp + 8 * j) : 0ull;
+            stage[(2 * j) * 64 + lane] = (u32)v;
+            stage[(2 * j + 1) * 64 + lane] = (u32)(v >> 32);
+        }
+        const u32 staged_bits = nd * 64;
+        const u32 maxbits = avail * 8;
+        const u32 u = (1u << H.logM) + ns + 1;
+        E[lane] = 0;
+        E[(ns + 1) * 64 + lane] = (u16)(u + 2);
+        stack[lane] = 0;  // row 0 is read speculatively while the stack is empty
+        u32* cum = g_cum + (u64)b * (NSP + 8);
+        // The loop body is one basic block: a lane that hits an error or runs out of staged bits
+        // only sets `stop` (1 = malformed, 2 = continue in the generic loop) and keeps going with
+        // frozen bit position -- every LDS / global index below is data independent or clamped, so
+        // that is harmless, and without exits the speculative stack and bounds reads at the top
+        // overlap the item's decode instead of following it.
+        u32 a = 0, n = ns, low = 1, high = u + 1, bitpos = 0, sp = 0, stop = 0;
+        for (u32 it = 0; it < ns; it++) {
+            const u32 h = (n + 1) >> 1;
+            const u32 n1 = h - 1, n2 = n - h, pe = a + h;
+            // next node (data independent): left child, else right child, else the pending one
+            const bool caseA = n1 != 0, caseB = !caseA && n2 != 0, caseC = !caseA && !caseB;
+            const u32 pc = stack[(sp ? sp - 1 : 0) * 64 + lane];
+            u32 wi = bitpos >> 5;
+            wi = wi < ANSX_PF_SW - 2 ? wi : ANSX_PF_SW - 2;
+            const u32 w0 = stage[wi * 64 + lane], w1 = stage[(wi + 1) * 64 + lane];
+            const u32 pa = pc >> 16, pn = pc & 0xFFFFu;
+            const u32 Ea = E[pa * 64 + lane], Eb = E[(pa + pn + 1) * 64 + lane];
+            const bool push = caseA && n2 != 0;
+            stack[(push ? sp : 20u) * 64 + lane] = (pe << 16) | n2;
+            // this item (read_center_mid, interp.hpp:47-63)
+            const u32 U = high - n2 - low - n1 + 1;
+            const u32 win = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);
+            const u32 Um1 = U - 1;
+            const u32 bb = 32 - __clz(Um1 | 1u) - (Um1 == 0 ? 1u : 0u);  // hi(U-1)+1; 0 for U == 1
+            const u32 lb = bb ? bb - 1 : 0;                               // bits of the first read
+            const u32 m = (u32)((1ull << bb) - U);
+            const u32 dh = U - ((1u << lb) & (bb ? ~0u : 0u));
+            u32 val = (win & ((1u << lb) - 1u)) + 1;
+            const bool big = (U != 1) && (val > m);
+            val = big ? (2 * val + ((win >> lb) & 1u)) - m - 1 : val;
+            val += dh;
+            if (val > U) val -= U;
+            if (U == 1) val = 1;
+            const u32 v = low + n1 - 1 + val;
+            // v <= u < 2^16 for a well-formed prelude
+            const bool bad = (U == 0) || (U > u + 1) || (bitpos > maxbits) || (v > 0xFFFFu);
+            const u32 now = (bitpos + 64 > staged_bits) ? 2u : (bad ? 1u : 0u);
+            stop = stop ? stop : now;
+            bitpos += (stop || U == 1) ? 0u : lb + (big ? 1u : 0u);
+            E[pe * 64 + lane] = (u16)v;
+            cum[pe] = v - 1;  // inc[pe - 1] (rewritten by the generic loop / ignored when stop != 0)
+            // descend
+            const u32 na = caseA ? a : (caseB ? pe : pa);
+            const u32 nn = caseA ? n1 : (caseB ? n2 : pn);
+            const u32 nlow = caseA ? low : (caseB ? v + 1 : Ea + 1);
+            const u32 nhigh = caseA ? v - 1 : (caseB ? high : Eb - 1);
+            sp = sp + (push ? 1u : 0u) - ((caseC && sp) ? 1u : 0u);
+            a = na, n = nn, low = nlow, high = nhigh;
+        }
+        err = (stop == 1) ? 1u : 0u;
+        slow = (stop == 2) ? 1u : 0u;
+        if (slow) err = parse_items_generic(H, NSP, b, lane, (uint4(*)[64])pf_smem, g_cum);
+    }
+    binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
     if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
 }
 

@@ -359,6 +359,30 @@ def test_corrupted_payload_never_faults(A, ctx):
             codec.decode(cont[:cut].copy() if cut else np.zeros(1, dtype=np.uint8), data.size)
 
 
+def test_prelude_parser_paths(A, ctx, monkeypatch):
+    """The decoder's prelude parser has a fast loop (alphabets whose interpolative values fit 16 bits,
+    first 512 prelude bytes staged in LDS), an in-kernel fallback for preludes that outgrow the
+    staged bytes, and a generic kernel.  A near-uniform alphabet of ~760 fold-1 symbols makes the
+    prelude of a 16 Ki-int block longer than 512 bytes, so some lanes take the fallback; the same
+    container must decode identically through the generic kernel."""
+    rng = np.random.default_rng(5)
+    n = 5 * 16384 + 777
+    third = n // 3
+    data = np.concatenate([rng.integers(0, 256, third), rng.integers(256, 1 << 16, third),
+                           rng.integers(1 << 16, 1 << 24, n - 2 * third)]).astype(np.uint32)
+    rng.shuffle(data)
+    codec = codec_for(A, ctx, ol.FOLD, 1, block_ints=16384, ckpt_interval=1024)
+    cont = codec.encode(data)
+    parts = check_container(A, cont, data, ol.FOLD, 1, 16384, 1024)
+    preludes = [ol.oracle_encode(ol.FOLD, 1, data[b * 16384:(b + 1) * 16384])[1].prelude_bytes
+                for b in range(parts["header"].nblocks)]
+    assert max(preludes) > 512 + 8, preludes      # the staged window is really exceeded
+    assert parts["header"].max_nsyms + (1 << parts["header"].max_log2_frame) + 3 <= 65535  # fast kernel eligible
+    assert np.array_equal(codec.decode(cont, n), data)
+    monkeypatch.setenv("ANSX_PARSE_GENERIC", "1")
+    assert np.array_equal(codec.decode(cont, n), data)
+
+
 @pytest.mark.parametrize("f", [1, 3])
 def test_rfold_large_blocks_and_whole_list(A, ctx, f):
     """Blocks longer than one LDS hash table (HBM hash-table path), incl. single-stream mode."""

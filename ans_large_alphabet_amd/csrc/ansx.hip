@@ -376,11 +376,16 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     // 16 bits and the per-lane arrays fit LDS (see k_parse_prelude_fast), generic loop otherwise.
     const size_t pf_e = std::max<size_t>(20480, rup(((size_t)max_ns + 2) * 128, 16));
     const size_t pf_lds = pf_e + (size_t)ANSX_PF_SW * 64 * 4 + 21 * 64 * 4;
+    u32 stage_words = ANSX_PF_SW;
+    if (const char* e = getenv("ANSX_PARSE_STAGE_WORDS")) {  // tests: force the in-kernel fallback
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 2 && v <= (long)ANSX_PF_SW) stage_words = (u32)v & ~1u;
+    }
     if ((u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024 && !getenv("ANSX_PARSE_GENERIC")) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
-            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, stage_words);
     } else {
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
             boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);

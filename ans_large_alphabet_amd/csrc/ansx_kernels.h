@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ con
 template <bool RFOLD>
 __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, u32 stage_words)
 {
     extern __shared__ __attribute__((aligned(16))) u8 pf_smem[];
     const u32 lane = threadIdx.x;
@@ -1497,7 +1497,8 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
         const u32 ns = H.ns;
         const u8* bp = H.stream + H.pos;
         const u32 avail = H.sbytes - H.pos;  // >= 32
-        const u32 nd = (avail >> 3) < ANSX_PF_SW / 2 ? (avail >> 3) : ANSX_PF_SW / 2;  // whole 8-byte pieces
+        // stage_words <= ANSX_PF_SW (the LDS allocation); smaller values only exercise the fallback
+        const u32 nd = (avail >> 3) < stage_words / 2 ? (avail >> 3) : stage_words / 2;  // whole 8-byte pieces
 #pragma unroll 8
         for (u32 j = 0; j < ANSX_PF_SW / 2; j++) {
             const u64 v = j < nd ? ld_u64_unaligned(bp + 8 * j) : 0ull;

@@ -718,9 +718,14 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
     return c;
 }
 
+// SMALL: alphabets of at most 1024 slots in frames up to 2^16 -- inc[] lives in LDS and is built
+// from the compact 4-byte table entries, and every thread keeps the codes of its <= 4 items from
+// the length pass for the packing pass (the workgroup is a latency chain otherwise: 16-byte table
+// entries, inc[] through global memory behind a fence, two tree descents per item).
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
-    const ansx_enc_entry* __restrict__ table, u32* __restrict__ incbuf, ansx_blk* __restrict__ blk,
-    u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
+    const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
 {
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
@@ -737,18 +742,39 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const u32 logM = B->logM;
     u32* off = lds32;         // [ns]
     u32* bits = lds32 + NSP;  // bit buffer
-    u32* inc = incbuf + (u64)b * NSP;
-    const ansx_enc_entry* tab = table + (u64)b * NSP;
-    for (u32 s = tid; s < ns; s += 256) {
-        ansx_enc_entry e = tab[s];
-        inc[s] = e.base + e.freq + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+    u32* inc = SMALL ? lds32 + 2 * NSP : incbuf + (u64)b * NSP;
+    if (SMALL) {
+        const u32* t32 = tab32 + (u64)b * NSP;
+        for (u32 s = tid; s < ns; s += 256) {
+            const u32 e = t32[s];
+            inc[s] = (e >> 16) + (e & 0xFFFFu) + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+        }
+    } else {
+        const ansx_enc_entry* tab = table + (u64)b * NSP;
+        for (u32 s = tid; s < ns; s += 256) {
+            ansx_enc_entry e = tab[s];
+            inc[s] = e.base + e.freq + s;
+        }
+        __threadfence_block();
     }
-    __threadfence_block();
     __syncthreads();
     const u64 u = ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
-    for (u32 i = tid; i < ns; i += 256) {
-        ansx_code c = interp_item(inc, ns, u, i);
-        off[c.rank] = c.len;
+    ansx_code mine[4];
+    if (SMALL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 i = tid + 256 * j;
+            mine[j].len = 0;
+            if (i < ns) {
+                mine[j] = interp_item(inc, ns, u, i);
+                off[mine[j].rank] = mine[j].len;
+            }
+        }
+    } else {
+        for (u32 i = tid; i < ns; i += 256) {
+            ansx_code c = interp_item(inc, ns, u, i);
+            off[c.rank] = c.len;
+        }
     }
     __syncthreads();
     // exclusive scan of off[0..ns)
@@ -766,14 +792,19 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const u32 nwords = (total_bits + 31) >> 5;
     for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
     __syncthreads();
-    for (u32 i = tid; i < ns; i += 256) {
-        ansx_code c = interp_item(inc, ns, u, i);
+    auto place = [&](const ansx_code& c) {
         if (c.len) {
             u32 o = off[c.rank];
             u32 w = o >> 5, sh = o & 31;
             atomicOr(&bits[w], c.code << sh);
             if (sh + c.len > 32) atomicOr(&bits[w + 1], c.code >> (32 - sh));
         }
+    };
+    if (SMALL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) place(mine[j]);
+    } else {
+        for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i));
     }
     __syncthreads();
     u8* out = scratch + (u64)b * scr_stride;

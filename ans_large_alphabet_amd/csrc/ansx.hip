@@ -373,7 +373,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32 max_block_bytes, u32* gflags, hipStream_t s)
+    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s)
 {
     const u32 T = fold_T(g.f);
     int rc;
@@ -407,17 +407,39 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
     const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16);
     if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !getenv("ANSX_DECODE_TABLE")) {
+        // per-quad stream rings when every segment of a full block has the same length; the (at
+        // most one) partial block of the container then reads its stream straight from HBM
+        // (measured on MI355X, 256 Mi ints: rings 0.73 vs 0.76 ms at 16 Ki / 1024, 0.73 vs 1.85 ms at
+        // 64 Ki / 1024 where the stream no longer fits; staged 0.60 vs 0.69 ms at 16 Ki / 512 -- the
+        // ring bookkeeping costs ~6 VALU per step, so it only pays when it frees a lot of LDS)
+        const size_t ring_lds = (size_t)(threads / 4) * ANSX_RING_BYTES;
+        const bool staged_fits = rs_tables + want_stream <= 52 * 1024;
+        const bool ring_ok = g.ckpt != 0 && g.block_ints % g.ckpt == 0 && g.ckpt % 4 == 0
+            && rs_tables + ring_lds <= 60 * 1024;
+        const bool ring_pays = !staged_fits || 10 * (rs_tables + want_stream) > 16 * (rs_tables + ring_lds);
+        const char* force = getenv("ANSX_DECODE_MODE");  // tests: "ring" | "staged"
+        const bool use_ring = ring_ok && (force ? !strcmp(force, "ring") : ring_pays);
+        if (use_ring) {
+            const size_t lds = rs_tables + ring_lds;
+            if (lds > 48 * 1024)
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LAUNCH(c, "k_decode", (k_decode_rank<RF, true>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
+                ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u64)cont_bytes, (const u32*)c->dec_cum.p,
+                (const uint4*)c->dec_info.p, gflags);
+            return ANSX_OK;
+        }
         size_t lds = rs_tables;
         u32 stream_cap = 0;
-        if (rs_tables + want_stream <= 52 * 1024 && !getenv("ANSX_NO_STREAM_LDS")) {
+        if (staged_fits && !getenv("ANSX_NO_STREAM_LDS")) {
             lds += want_stream;
             stream_cap = (u32)want_stream;
         }
         if (lds > 48 * 1024)
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF>,
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LAUNCH(c, "k_decode", (k_decode_rank<RF>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
-            ck_off, payload_off, d_out, maxM, max_ns, stream_cap, (const u32*)c->dec_cum.p,
+        LAUNCH(c, "k_decode", (k_decode_rank<RF, false>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
+            ck_off, payload_off, d_out, maxM, max_ns, (u64)stream_cap, (const u32*)c->dec_cum.p,
             (const uint4*)c->dec_info.p, gflags);
         return ANSX_OK;
     }
@@ -506,6 +528,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     const u64* ck_state = nullptr;
     const u32* ck_off = nullptr;
     u64 payload_off;
+    u64 in_bytes_payload = 0;  // bytes of block streams behind payload_off (bounds the ring decoder reads)
     if (P.plain) {
         // one reference stream: copy behind a 16-byte guard (the decoder reads 8 bytes below
         // its cursor) and peek max_sym / log2 M on the host
@@ -549,6 +572,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         boff = boff_ws;
         payload_off = 16;
         max_block_bytes = (u32)in_bytes;
+        in_bytes_payload = in_bytes;
     } else {
         u8* hp = (u8*)c->h_pin + 64;
         if (in_bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
@@ -577,6 +601,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         ck_state = (const u64*)(d_in + P.lay.ckstate_off);
         ck_off = (const u32*)(d_in + P.lay.ckoff_off);
         payload_off = H.payload_offset;
+        in_bytes_payload = H.payload_bytes;
         LAUNCH(c, "k_validate_index", k_validate_index, (P.g.nblocks + 255) / 256, 256, 0, s, P.g, boff,
             H.payload_bytes, gflags);
         // the index must be sane before any block is touched
@@ -587,10 +612,10 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, gflags, s);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, gflags, s);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

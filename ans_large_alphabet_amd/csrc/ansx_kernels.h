@@ -544,15 +544,19 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     const double thr = B->thr;
     int prev = B->prev;
     int chosen = -2;
+    // all candidates' results in one round trip (lane t holds attempt t), then the sequential rule
+    uint4 mt = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < ANSX_ATTEMPTS) mt = *(const uint4*)(attMeta + ((u64)b * ANSX_ATTEMPTS + lane) * 4);
     for (u32 t = 0; t < ANSX_ATTEMPTS; t++) {
-        const u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;
-        if (!meta[0]) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
+        const u32 m0 = __shfl(mt.x, (int)t), m1 = __shfl(mt.y, (int)t);
+        const u32 m2 = __shfl(mt.z, (int)t), m3 = __shfl(mt.w, (int)t);
+        if (!m0) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
         const u32 T = batch * ANSX_ATTEMPTS + t;
-        if (meta[1] >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
+        if (m1 >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
             chosen = prev;
             break;
         }
-        const double XH = ansx_bits_to_f64((u64)meta[2] | ((u64)meta[3] << 32));
+        const double XH = ansx_bits_to_f64((u64)m2 | ((u64)m3 << 32));
         if (XH < thr) {  // ans_util.hpp:149
             chosen = (int)T;
             break;
@@ -1602,14 +1606,25 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
 
 // 8 stream bytes ending at byte offset `end` (exclusive): from the LDS-staged copy (aligned
 // words + v_alignbyte) or straight from global memory (one unaligned 8-byte load)
-template <bool STREAM_LDS>
+#define ANSX_RING_BYTES 512
+template <int MODE>
 __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end)
 {
-    if (STREAM_LDS) {
+    if (MODE == 1) {
         // lds_stream word 0 holds stream bytes [-8,-4): byte a of the stream is at lds byte a+8
         const u32 a = (u32)end;  // = (end - 8) + 8
         const u32 w = a >> 2, sh = a & 3;
         const u32 w0 = lds_stream[w], w1 = lds_stream[w + 1], w2 = lds_stream[w + 2];
+        const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        return ((u64)hi << 32) | lo;
+    } else if (MODE == 2) {
+        // lds_stream = this quad's ring: stream byte s lives at ring byte s & (ANSX_RING_BYTES-1)
+        const u32 a = (u32)(end - 8);
+        const u32 sh = a & 3;
+        const u32 i0 = (a >> 2) & (ANSX_RING_BYTES / 4 - 1);
+        const u32 i1 = (i0 + 1) & (ANSX_RING_BYTES / 4 - 1), i2 = (i0 + 2) & (ANSX_RING_BYTES / 4 - 1);
+        const u32 w0 = lds_stream[i0], w1 = lds_stream[i1], w2 = lds_stream[i2];
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
         const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
         return ((u64)hi << 32) | lo;
@@ -1682,7 +1697,7 @@ struct dec_quad_const {
     u32 ql8;     // 8 * ql
     u32 lomask;  // (1 << 8 ql) - 1
 };
-template <bool STREAM_LDS, typename LUT>
+template <int STREAM_LDS, typename LUT>
 __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_quad_const qc, u32 logM, u32 mask,
     u64 Lb, const LUT& lut, const u8* __restrict__ stream, const u32* lds_stream)
 {
@@ -1748,13 +1763,13 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                 for (; i + 4 <= steps0; i += 4) {
 #pragma unroll
                     for (u32 u = 0; u < 4; u++)
-                        op[4 * (i + u)] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                        op[4 * (i + u)] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
                 }
                 for (; i < steps0; i++)
-                    op[4 * i] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                    op[4 * i] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
             } else {
                 for (u32 i = 0; i < steps; i++)
-                    op[4 * i] = dec_step<true>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                    op[4 * i] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
             }
         } else {
             // The cursor walks down the stream ~4.5 bytes per step; pull the next 512 bytes
@@ -1770,16 +1785,118 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                     pf = ld_u32_unaligned(stream + (a & ~3));
                     pf_front -= 512;
                 }
-                o[i + ql] = dec_step<false>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                o[i + ql] = dec_step<0>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
             }
             asm volatile("" ::"v"(pf));
         }
         if (seg == nseg - 1) {  // tail symbols come from state 0 = lane 3 (ans_fold.hpp:307-310)
             for (u32 i = nfull; i < nb; i++) {
-                u32 val = dec_step<STREAM_LDS>(st, q, ql == 3, qc, logM, mask, Lb, lut, stream, lds_stream);
+                u32 val = dec_step<STREAM_LDS ? 1 : 0>(st, q, ql == 3, qc, logM, mask, Lb, lut, stream, lds_stream);
                 if (ql == 3) o[i] = val;
             }
         }
+    }
+}
+
+// ---- per-quad stream ring ------------------------------------------------------------------
+// Instead of the whole block stream (~20 KB at the defaults, which caps a CU at 5 blocks in
+// flight), every quad keeps a 512-byte window of ITS segment's bytes in LDS; stream byte s lives
+// at ring byte s & 511.  The cursor p walks down at most 28 bytes per step and a step reads down
+// to p - 32.  Every 4 steps ("check"): the 128 bytes requested at the previous check are written
+// into the ring (lo -= 128), and if less than 368 bytes remain below p another 128 are requested
+// (two 16-byte buffer loads per lane; a lane with nothing to fetch gets an out-of-range offset).
+// Invariant: p - lo >= 256 after every landing, so the 4 steps of an interval (<= 112 bytes) never
+// leave the window, and the window (< 496 bytes before a landing of 128 onto consumed bytes) fits.
+// The loads are inline asm, invisible to hipcc's waitcnt pass, and are consumed behind
+// s_waitcnt vmcnt(4): vmcnt is in-order and exactly the interval's 4 output stores are younger,
+// so the wait never touches them (letting the compiler wait for these loads costs a drain of the
+// output stores per refill -- the reason an earlier ring attempt was slower than whole-stream
+// staging).  Used when every segment of the block has the same length (all full blocks).
+typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
+struct dec_ring_desc {
+    ansx_u32x4 rsrc;  // buffer descriptor over [stream - backoff, stream + sbytes + slack) inside the container
+    int backoff;  // stream offset s is at buffer offset s + backoff
+};
+__device__ __forceinline__ ansx_u32x4 ring_load16(const dec_ring_desc& D, int s, bool want)
+{
+    const int off = s + D.backoff;
+    const u32 voff = (want && off >= 0) ? (u32)off : ANSX_BUF_OOB;
+    ansx_u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(D.rsrc) : "memory");
+    return r;
+}
+
+template <typename LUT>
+__device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 sbytes, u32 tid, u32 nt,
+    u32 logM, const LUT& lut, const u8* __restrict__ stream, u32* rings, const dec_ring_desc& D,
+    const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o)
+{
+    const u32 nseg = g.block_ints / g.ckpt;  // uniform segments (checked by the caller)
+    const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
+    const dec_quad_const qc = { 8 * ql, (1u << (8 * ql)) - 1u };
+    const u64 Lb = (u64)16 << logM;
+    const u32 mask = (1u << logM) - 1;
+    u32* ring = rings + quad * (ANSX_RING_BYTES / 4);
+    u8* ring8 = (u8*)ring;
+    const u32 steps = g.ckpt >> 2;
+    for (u32 seg = quad; seg < nseg; seg += nq) {
+        u64 st;
+        int p;
+        if (seg == 0) {  // ans_fold.hpp:289-295: states 3,2,1,0 from the end
+            st = ld_u64_unaligned(stream + sbytes - 32 + 8 * (3 - ql)) + Lb;
+            p = (int)sbytes - 32;
+        } else {
+            const u64 idx = (u64)b * g.nckf + (seg - 1);
+            st = ckpt_state[idx * 4 + (3 - ql)];
+            u32 po = ckpt_off[idx];
+            p = (int)(po < sbytes ? po : sbytes);
+        }
+        u32 q = (u32)(-p);
+        // initial window [lo, lo + 512), lo = (p - 384) rounded down to 32 (a lane's two 16-byte
+        // pieces of a refill then never straddle the ring's end): 8 pieces per lane
+        int lo = (p - 384) & ~31;
+        {
+            ansx_u32x4 r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = ring_load16(D, lo + 128 * (int)ql + 16 * j, true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                // keep the data dependence on the asm loads visible after the wait
+                asm volatile("" : "+v"(r[j]));
+                *(ansx_u32x4*)(ring8 + ((u32)(lo + 128 * (int)ql + 16 * j) & (ANSX_RING_BYTES - 1))) = r[j];
+            }
+        }
+        u32* op = o + seg * g.ckpt + ql;
+        bool pending = false;
+        ansx_u32x4 r0 = { 0u, 0u, 0u, 0u }, r1 = r0;
+        u32 i = 0;
+        for (; i + 4 <= steps; i += 4) {
+            // ---- check: land the previous request, decide the next one
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1)::"memory");
+            if (pending) {
+                lo -= 128;
+                const u32 d0 = (u32)(lo + 32 * (int)ql) & (ANSX_RING_BYTES - 1);
+                *(ansx_u32x4*)(ring8 + d0) = r0;
+                *(ansx_u32x4*)(ring8 + d0 + 16) = r1;  // 32-byte aligned pair: no wrap inside
+            }
+            const int cur = -(int)q;
+            pending = (cur - lo) < 368;
+            r0 = ring_load16(D, lo - 128 + 32 * (int)ql, pending);
+            r1 = ring_load16(D, lo - 128 + 32 * (int)ql + 16, pending);
+#pragma unroll
+            for (u32 u = 0; u < 4; u++)
+                op[4 * (i + u)] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+        }
+        // leftover steps (ckpt not a multiple of 16): land what is in flight first
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
+        if (pending) {
+            lo -= 128;
+            const u32 d0 = (u32)(lo + 32 * (int)ql) & (ANSX_RING_BYTES - 1);
+            *(ansx_u32x4*)(ring8 + d0) = r0;
+            *(ansx_u32x4*)(ring8 + d0 + 16) = r1;
+        }
+        for (; i < steps; i++) op[4 * i] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
     }
 }
 
@@ -1800,11 +1917,12 @@ __device__ __forceinline__ void dec_stage_stream(u32* lds_stream, const u8* __re
 // waits on the in-order vmcnt behind the outstanding output stores.)
 //
 // k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
-template <bool RFOLD>
+// RING: per-quad stream rings instead of the staged stream (stream_cap is then the container size).
+template <bool RFOLD, bool RING>
 __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
     const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
-    u32 max_ns, u32 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
+    u32 max_ns, u64 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
     u32* __restrict__ gflags)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1834,7 +1952,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u32 W = M >= 32 ? M / 32 : 1;
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
     if (tid == 0) sh_bad = 0;
-    const bool st_lds = (sbytes + 24 <= stream_cap);
+    const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
     if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
     __syncthreads();
     // wave 0: frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1),
@@ -1917,7 +2035,20 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     lut.ent = ent;
     lut.pval = pval;
     u32* o = outp + (u64)b * g.block_ints;
-    if (st_lds)
+    if (RING && nb == g.block_ints) {  // full block: all segments have g.ckpt ints (host-checked)
+        // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
+        // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
+        const u64 sabs = payload_off + boff;  // stream offset inside the container
+        dec_ring_desc D;
+        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
+        const u8* base = cont + (sabs - (u64)D.backoff);
+        u64 span = (u64)D.backoff + sbytes + 64;
+        const u64 room = stream_cap - (sabs - (u64)D.backoff);  // container bytes from base on
+        if (span > room) span = room;
+        const u64 ba = (u64)(uintptr_t)base;
+        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
+        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, lds_stream, D, ckpt_state, ckpt_off, o);
+    } else if (st_lds)
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
         dec_segments<false>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);

@@ -359,6 +359,25 @@ def test_corrupted_payload_never_faults(A, ctx):
             codec.decode(cont[:cut].copy() if cut else np.zeros(1, dtype=np.uint8), data.size)
 
 
+@pytest.mark.parametrize("kind,f", [(ol.FOLD, 1), (ol.RFOLD, 1), (ol.FOLD, 3)])
+def test_decoder_stream_modes(A, ctx, monkeypatch, kind, f):
+    """The block decoder reads the stream through per-quad LDS rings, a staged copy of the whole
+    block stream, or straight from HBM, with rank/select or slot->symbol tables: every combination
+    must return the same ints (the default picks by LDS footprint)."""
+    n = 3 * 16384 + 4100  # full blocks + a partial one
+    data = ol.gen_inputs("zipf20s1.2", n, seed=91)
+    data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    for block, ckpt in ((16384, 1024), (16384, 256), (8192, 2048)):
+        codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ckpt)
+        cont = codec.encode(data)
+        for env in ({}, {"ANSX_DECODE_MODE": "ring"}, {"ANSX_DECODE_MODE": "staged"},
+                    {"ANSX_DECODE_MODE": "staged", "ANSX_NO_STREAM_LDS": "1"}, {"ANSX_DECODE_TABLE": "1"}):
+            with monkeypatch.context() as m:
+                for k, v in env.items():
+                    m.setenv(k, v)
+                assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, env)
+
+
 def test_prelude_parser_paths(A, ctx, monkeypatch):
     """The decoder's prelude parser has a fast loop (alphabets whose interpolative values fit 16 bits,
     the first 512 prelude bytes staged in LDS), an in-kernel fallback for lanes whose prelude

@@ -211,7 +211,7 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
         size_t lds = 6 * (size_t)ANSX_RF_SLOTS + 8 * (size_t)(T < 512 ? 512 : T);  // also holds a 1024-bin histogram
         HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash, g.nblocks, 256, lds, s, d_in, g, mapped, mostfreq,
+        LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash, g.nblocks, 1024, lds, s, d_in, g, mapped, mostfreq,
             blk, gflags);
         return ANSX_OK;
     }

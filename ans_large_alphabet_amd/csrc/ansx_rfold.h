@@ -33,11 +33,11 @@ __device__ __forceinline__ u32 lds_upper_bound(const u32* a, u32 n, u32 v)
     return lo;
 }
 
-template <typename K> __device__ __forceinline__ void lds_bitonic_sort(K* keys, u32 N2, u32 tid)
+template <typename K> __device__ __forceinline__ void lds_bitonic_sort(K* keys, u32 N2, u32 tid, u32 nt = 256)
 {
     for (u32 k = 2; k <= N2; k <<= 1) {
         for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < N2; i += 256) {
+            for (u32 i = tid; i < N2; i += nt) {
                 u32 ixj = i ^ j;
                 if (ixj > i) {
                     bool asc = (i & k) == 0;
@@ -185,14 +185,16 @@ __global__ __launch_bounds__(256) void k_rfold_remap(const u32* __restrict__ in,
 
 __device__ __forceinline__ u32 rf_slot(u32 v) { return (u32)(((u64)(v * 2654435761u) * ANSX_RF_SLOTS) >> 32); }
 
-__global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict__ in, ansx_geo g,
+// Launched with 1024 threads: the table occupies most of a CU's LDS, so this one workgroup is all
+// the latency hiding its ~10 passes over the table get (8.9 -> see DESIGN.md with 256 threads).
+__global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict__ in, ansx_geo g,
     u32* __restrict__ mapped, u32* __restrict__ mostfreq, ansx_blk* __restrict__ blk,
     u32* __restrict__ gflags)
 {
     extern __shared__ u8 smem_rh[];
     __shared__ u32 sh_cnt;
     __shared__ u32 sh_max;
-    const u32 tid = threadIdx.x;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
     const u32 b = blockIdx.x;
     const u32 nb = geo_block_n(g, b);
     const u32 T = fold_T(g.f);
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     u64* sel = (u64*)(smem_rh + 6 * (size_t)ANSX_RF_SLOTS);        // [T]
     const u32* src = in + (u64)b * g.block_ints;
     u32* dst = mapped + (u64)b * g.block_ints;
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) keys[i] = ANSX_RF_EMPTY;
-    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += 256) cnt32[i] = 0;
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) keys[i] = ANSX_RF_EMPTY;
+    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += nt) cnt32[i] = 0;
     if (tid == 0) {
         sh_cnt = 0;
         sh_max = 0;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     auto count_of = [&](u32 slot) -> u32 { return (cnt32[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu; };
     // ---- insert: value -> count (counts <= 16384 fit 16 bits)
     u32 lmax = 0, ldistinct = 0;
-    for (u32 i = tid; i < nb; i += 256) {
+    for (u32 i = tid; i < nb; i += nt) {
         const u32 v = src[i];
         lmax = v > lmax ? v : lmax;
         u32 slot = rf_slot(v);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     const u32 sigma = sh_cnt;
     const u32 vmax = sh_max;
     if (sigma < T) {  // ans_reorder_fold.hpp:94-97: identity mapping, flag 0
-        for (u32 i = tid; i < nb; i += 256) dst[i] = src[i];
+        for (u32 i = tid; i < nb; i += nt) dst[i] = src[i];
         if (tid == 0) {
             blk[b].flag = 0;
             if (vmax >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
@@ -285,20 +287,20 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     };
     auto clear_hist = [&](u32 nbins) {
         __syncthreads();
-        for (u32 i = tid; i < nbins; i += 256) hist[i] = 0;
+        for (u32 i = tid; i < nbins; i += nt) hist[i] = 0;
         __syncthreads();
     };
     u32 before;
     // ---- c*: level 1 (count >> 7), level 2 (count & 127), scanned from the top
     clear_hist(256);
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
         const u32 c = count_of(i);
         if (c) atomicAdd(&hist[c >> 7], 1u);
     }
     const u32 B1 = find_bucket(129, T, true, &before);
     const u32 above1 = before;
     clear_hist(128);
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
         const u32 c = count_of(i);
         if (c && (c >> 7) == B1) atomicAdd(&hist[c & 127], 1u);
     }
@@ -311,14 +313,14 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     u32 vstar = 0xFFFFFFFFu;  // values at the threshold count are selected iff value <= vstar
     if (ties > K) {
         clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
             const u32 k = keys[i];
             if (k != ANSX_RF_EMPTY && count_of(i) == cstar) atomicAdd(&hist[k >> 20], 1u);
         }
         const u32 V1 = find_bucket(1024, K, false, &before);
         const u32 k1 = K - before;
         clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
             const u32 k = keys[i];
             if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 20) == V1) atomicAdd(&hist[(k >> 10) & 1023], 1u);
         }
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
         const u32 k2 = k1 - before;
         const u32 hi20 = (V1 << 10) | V2;
         clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
             const u32 k = keys[i];
             if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 10) == hi20) atomicAdd(&hist[k & 1023], 1u);
         }
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
     __syncthreads();
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += 256) {
+    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
         const u32 k = keys[i];
         if (k == ANSX_RF_EMPTY) continue;
         const u32 c = count_of(i);
@@ -346,11 +348,11 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
         }
     }
     __syncthreads();
-    lds_bitonic_sort<u64>(sel, T, tid);
-    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += 256) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
+    lds_bitonic_sort<u64>(sel, T, tid, nt);
+    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += nt) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
     __syncthreads();
     u32* mf = mostfreq + (u64)b * T;
-    for (u32 r = tid; r < T; r += 256) {
+    for (u32 r = tid; r < T; r += nt) {
         const u32 v = (u32)sel[r];
         mf[r] = v;  // ans_reorder_fold.hpp:104-105
         u32 slot = rf_slot(v);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_rfold_remap_hash(const u32* __restrict_
         atomicAnd(&cnt32[slot >> 1], ~(0xFFFFu << (16 * (slot & 1))) | (r << (16 * (slot & 1))));
     }
     __syncthreads();
-    for (u32 i = tid; i < nb; i += 256) {
+    for (u32 i = tid; i < nb; i += nt) {
         const u32 v = src[i];
         u32 slot = rf_slot(v);
         while (keys[slot] != v) slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;

@@ -342,12 +342,18 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
     // (its emitted-byte stores go through a buffer descriptor spanning the wave's 16 scratch slots:
     // 31-bit offsets)
-    if (max_logM <= 16 && enc_lds <= 40 * 1024 && (u64)scr_stride * 16 < 0x7FFFFF00ull) {
-        LAUNCH(c, "k_encode", (k_encode<true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+    const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
+    if (f64_ok && enc_lds <= 40 * 1024) {
+        LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);
+    } else if (f64_ok && !getenv("ANSX_ENCODE_GTAB16")) {
+        // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
+        LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
+            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off);
     } else {
-        LAUNCH(c, "k_encode_gtab", (k_encode<false>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
+        LAUNCH(c, "k_encode_gtab", (k_encode<0>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);
     }

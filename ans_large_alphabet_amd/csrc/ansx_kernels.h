@@ -1051,6 +1051,8 @@ template <> struct enc_tab<false> {
     }
     typedef enc_ent entp;
     __device__ __forceinline__ enc_ent getp(const ansx_map& mp, u32 x, double, u32) const { return get(mp, x); }
+    __device__ __forceinline__ u32 fetchp(const ansx_map&, u32) const { return 0; }
+    __device__ __forceinline__ enc_ent finishp(const ansx_map& mp, u32 x, u32, double, u32) const { return get(mp, x); }
     __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent& e, const enc_quad_const&, u32 ql,
         u32 logM, __amdgpu_buffer_rsrc_t, u8* __restrict__ out) const
     {
@@ -1101,6 +1103,28 @@ template <> struct enc_tab<true> {
         r.kpos = r.k << ql8;
         return r;
     }
+    // MODE 2 of k_encode: the table word comes from HBM through an inline-asm load (the caller owns
+    // the vmcnt wait), conversion happens one sub-batch later
+    __device__ __forceinline__ u32 fetchp(const ansx_map& mp, u32 x) const
+    {
+        const u32 k = map_nbytes(mp, x);
+        u32 e;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(e) : "v"(t + map_sym(mp, x, k)) : "memory");
+        return e;
+    }
+    __device__ __forceinline__ enc_ent_n finishp(const ansx_map& mp, u32 x, u32 e, double Md, u32 ql8) const
+    {
+        enc_ent_n r;
+        r.k = map_nbytes(mp, x);
+        r.Fd = (double)(e & 0xFFFFu);
+        r.based = (double)(e >> 16);
+        const double r0 = __builtin_amdgcn_rcp(r.Fd);
+        r.rcp = __builtin_fma(__builtin_fma(-r.Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);  // see getp
+        r.thr = r.Fd * 68719476736.0;
+        r.MF = Md - r.Fd;
+        r.kpos = r.k << ql8;
+        return r;
+    }
     __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent_n& e, const enc_quad_const& qc,
         u32, u32, __amdgpu_buffer_rsrc_t rsrc, u8* __restrict__) const
     {
@@ -1113,7 +1137,12 @@ template <> struct enc_tab<true> {
 #define ANSX_ENC_U 8    // table entries per lane fetched ahead
 #define ANSX_ENC_XB 32  // inputs per lane fetched ahead (one super-batch)
 
-template <bool LDS_TABLE>
+// MODE 0: 16-byte table entries in HBM, integer state (any frame size)
+// MODE 1: compact tables of the wave's 16 blocks in LDS, f64 state, branch-free step (M <= 2^16)
+// MODE 2: compact tables in HBM (alphabets too large for LDS), otherwise as MODE 1: the entries of
+//         the next sub-batch are fetched with inline-asm loads and consumed behind exact vmcnt
+//         waits (24 = the stores of one sub-batch, 32 = the input prefetch of a super-batch)
+template <int MODE>
 __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
@@ -1122,6 +1151,8 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     extern __shared__ u32 lds_tab[];
     const u32 gt = blockIdx.x * 64 + threadIdx.x;
     const u32 b = gt >> 2, ql = gt & 3;
+    constexpr bool LDS_TABLE = MODE == 1;
+    constexpr bool F64 = MODE != 0;
     if (LDS_TABLE) {
         // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries)
         const u32 b0 = blockIdx.x * 16;
@@ -1142,8 +1173,9 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     }
     const u32 nb = geo_block_n(g, b);
     const u32* src = in + (u64)b * g.block_ints;
-    enc_tab<LDS_TABLE> tab;
-    if constexpr (LDS_TABLE) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
+    enc_tab<F64> tab;
+    if constexpr (MODE == 1) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
+    else if constexpr (MODE == 2) tab.t = tab32 + (u64)b * NSP;
     else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
     // buffer view of the wave's 16 scratch slots (the host guarantees 16 * scr_stride < 2^31 for
@@ -1200,15 +1232,21 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         const bool ck_per_batch = (cg % ANSX_ENC_U) == 0;
         const u32* base = src + 3 - ql;
         const enc_quad_const qc = { 4u << (8 * ql), (1u << (8 * ql)) - 1u };
-        if constexpr (LDS_TABLE) {
+        if constexpr (F64) {
             pbias = obase;
             L.p += obase;
         }
         u32 xa[ANSX_ENC_XB], xb[ANSX_ENC_XB];
 #pragma unroll
         for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = base[4 * (gi - 1 - j)];
+        u32 raw1[ANSX_ENC_U] = {};
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j]);
+        }
         while (gi) {
             const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
+            const bool any_next = __builtin_amdgcn_ballot_w64(top >= 2 * ANSX_ENC_XB) != 0;  // wave uniform
             if (top >= 2 * ANSX_ENC_XB) {
                 // Issued as inline asm so that hipcc's waitcnt pass does not see these loads: it
                 // would put s_waitcnt vmcnt(31..0) in front of their first use, and because vmcnt
@@ -1224,18 +1262,41 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                                  : "v"(base + 4 * (top - ANSX_ENC_XB - 1 - j))
                                  : "memory");
             }
-            typename enc_tab<LDS_TABLE>::entp e1[ANSX_ENC_U];
+            typename enc_tab<F64>::entp e1[ANSX_ENC_U];
+            if constexpr (MODE != 2) {
 #pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.getp(f, xa[j], Md, 8 * ql);
+                for (int j = 0; j < ANSX_ENC_U; j++) e1[j] = tab.getp(f, xa[j], Md, 8 * ql);
+            }
 #pragma unroll
             for (int sb = 0; sb < ANSX_ENC_XB / ANSX_ENC_U; sb++) {
-                typename enc_tab<LDS_TABLE>::entp e0[ANSX_ENC_U];
-#pragma unroll
-                for (int j = 0; j < ANSX_ENC_U; j++) e0[j] = e1[j];
-                if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
+                typename enc_tab<F64>::entp e0[ANSX_ENC_U];
+                if constexpr (MODE == 2) {
+                    // raw1 = table words of this sub-batch, requested one sub-batch ago (sb >= 1: the
+                    // 24 stores of that sub-batch are the only younger operations) or at the end of
+                    // the previous super-batch (sb == 0: only the input prefetch above is younger)
+                    if (sb == 0) {
+                        if (any_next) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                    }
+                    asm volatile("" : "+v"(raw1[0]), "+v"(raw1[1]), "+v"(raw1[2]), "+v"(raw1[3]), "+v"(raw1[4]),
+                                 "+v"(raw1[5]), "+v"(raw1[6]), "+v"(raw1[7]));
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++)
-                        e1[j] = tab.getp(f, xa[(sb + 1) * ANSX_ENC_U + j], Md, 8 * ql);
+                        e0[j] = tab.finishp(f, xa[sb * ANSX_ENC_U + j], raw1[j], Md, 8 * ql);
+                    if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
+#pragma unroll
+                        for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[(sb + 1) * ANSX_ENC_U + j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ANSX_ENC_U; j++) e0[j] = e1[j];
+                    if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
+#pragma unroll
+                        for (int j = 0; j < ANSX_ENC_U; j++)
+                            e1[j] = tab.getp(f, xa[(sb + 1) * ANSX_ENC_U + j], Md, 8 * ql);
+                    }
                 }
                 const u32 sbtop = top - sb * ANSX_ENC_U;  // groups sbtop-1 ... sbtop-U
                 if (ck_per_batch) {
@@ -1264,6 +1325,12 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                              "+v"(xb[j + 5]), "+v"(xb[j + 6]), "+v"(xb[j + 7]));
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = xb[j];
+            if constexpr (MODE == 2) {
+                if (gi) {
+#pragma unroll
+                    for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j]);
+                }
+            }
         }
         L.p -= pbias;
         pbias = 0;

@@ -299,7 +299,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
     if ((size_t)NSP * 8 + 64 > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<false>,
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
         (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
@@ -326,11 +326,17 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     }
     // K3
     if (NSP <= 1024 && max_logM <= 16) {
-        LAUNCH(c, "k_write_prelude", (k_write_prelude<true>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
+            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, mostfreq);
+    } else if (NSP <= 4096 && max_logM <= 16) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)((size_t)NSP * 12 + 64)));
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq);
     } else {
-        LAUNCH(c, "k_write_prelude", (k_write_prelude<false>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq);
     }

@@ -722,15 +722,16 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
     return c;
 }
 
-// SMALL: alphabets of at most 1024 slots in frames up to 2^16 -- inc[] lives in LDS and is built
-// from the compact 4-byte table entries, and every thread keeps the codes of its <= 4 items from
-// the length pass for the packing pass (the workgroup is a latency chain otherwise: 16-byte table
-// entries, inc[] through global memory behind a fence, two tree descents per item).
-template <bool SMALL>
+// IPT > 0: alphabets of at most 256 * IPT slots in frames up to 2^16 -- inc[] lives in LDS and is
+// built from the compact 4-byte table entries, and every thread keeps the codes of its <= IPT items
+// from the length pass for the packing pass (the workgroup is a latency chain otherwise: 16-byte
+// table entries, inc[] through global memory behind a fence, two tree descents per item).
+template <int IPT>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
 {
+    constexpr bool SMALL = IPT > 0;
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
     const u32 tid = threadIdx.x;
@@ -763,10 +764,10 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     }
     __syncthreads();
     const u64 u = ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
-    ansx_code mine[4];
+    ansx_code mine[SMALL ? IPT : 1];
     if (SMALL) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < (SMALL ? IPT : 1); j++) {
             const u32 i = tid + 256 * j;
             mine[j].len = 0;
             if (i < ns) {
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     };
     if (SMALL) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) place(mine[j]);
+        for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
         for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i));
     }

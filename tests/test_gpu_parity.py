@@ -378,6 +378,23 @@ def test_decoder_stream_modes(A, ctx, monkeypatch, kind, f):
                 assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, env)
 
 
+def test_encoder_table_modes(A, ctx, monkeypatch):
+    """Alphabets too large for the LDS-table encoder take the compact-table-from-HBM mode (f64 state,
+    branch-free step, hand-counted vmcnt waits); ANSX_ENCODE_GTAB16 forces the older 16-byte-entry
+    integer-state kernel.  Both must write byte-identical containers (and equal the oracle)."""
+    n = 4 * 16384 + 1234
+    for fam, f in (("zipf24", 3), ("uniform20", 5), ("sparse_large", 3)):
+        data = ol.gen_inputs(fam, n, seed=7 + f)
+        codec = codec_for(A, ctx, ol.FOLD, f, block_ints=16384, ckpt_interval=1024)
+        cont = codec.encode(data)
+        check_container(A, cont, data, ol.FOLD, f, 16384, 1024)
+        with monkeypatch.context() as m:
+            m.setenv("ANSX_ENCODE_GTAB16", "1")
+            cont16 = codec.encode(data)
+        assert np.array_equal(cont, cont16), (fam, f)
+        assert np.array_equal(codec.decode(cont, n), data)
+
+
 def test_prelude_parser_paths(A, ctx, monkeypatch):
     """The decoder's prelude parser has a fast loop (alphabets whose interpolative values fit 16 bits,
     the first 512 prelude bytes staged in LDS), an in-kernel fallback for lanes whose prelude

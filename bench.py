@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256 * (1 << 20), help="ints per GPU")
+    ap.add_argument("--n", "--ints", dest="n", type=int, default=256 * (1 << 20), help="ints per GPU")
     ap.add_argument("--codec", default="fold", choices=["fold", "rfold"])
     ap.add_argument("--fidelity", type=int, default=1)
     ap.add_argument("--dist", default="zipf20s1.2", help="zipf<log2 sigma>s<exponent> | uniform256")
@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64 * (1 << 20))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N > 1 control-flow rehearsal on ONE GPU: gloo backend, every rank on cuda:0, "
+                         "containers gathered through host copies (not a measurement)")
     args = ap.parse_args()
 
     import torch
@@ -168,6 +171,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -175,7 +180,10 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL on ROCm
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL on ROCm
 
     import ans_large_alphabet_amd as A
 
@@ -194,26 +202,40 @@ def main():
     else:
         raise SystemExit("unknown --dist")
     cap = min(codec.bound(n), 8 * n + (64 << 20))
-    d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+    # N > 1: two container buffers, so that the gather of step k (RCCL send/recv on its own stream)
+    # overlaps this rank's decode of step k AND its encode of step k+1; a buffer is reused only
+    # after the transfer that reads it has been waited for
+    outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
+    d_out = outs[0]
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
     from ans_large_alphabet_amd import dist as adist
 
+    state = {"k": 0, "pending": [], "keep": None}
+
+    def drain():
+        for w in state["pending"]:
+            w.wait()
+        state["pending"], state["keep"] = [], None
+
     def step():
-        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
-        works = []
+        out = outs[state["k"] % len(outs)]
+        state["k"] += 1
+        nb = codec.encode_dev(d_in.data_ptr(), n, out.data_ptr(), cap, stream=stream)
+        works, buf = [], None
         if dist is not None:
             # concatenate the per-GPU containers on rank 0: 8-byte sizes first, then one direct
-            # send per rank (each sender uses its own xGMI link to the root); the transfer runs
-            # on RCCL's stream while this rank decodes its own container below
-            _buf, _sizes, works = adist.gather_containers(d_out, nb, dst=0, async_op=True)
-        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
-        for w in works:
-            w.wait()
+            # send per rank (each sender uses its own xGMI link to the root)
+            src = out[:nb].cpu() if args.rehearse_gloo else out
+            buf, _sizes, works = adist.gather_containers(src, nb, dst=0, async_op=True)
+        codec.decode_dev(out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+        drain()  # the PREVIOUS step's transfer (it read the other buffer)
+        state["pending"], state["keep"] = works, buf
         return nb
 
     def sync_all():
+        drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -229,7 +251,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ok = bool(torch.equal(d_back, d_in))

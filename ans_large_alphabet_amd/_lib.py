@@ -21,7 +21,7 @@ EXPORTS = [
     "ansx_init", "ansx_destroy", "ansx_strerror", "ansx_last_hip_error", "ansx_codec_name",
     "ansx_bound", "ansx_encode", "ansx_decode", "ansx_encode_dev", "ansx_decode_dev",
     "ansx_container_info", "ansx_profile_enable", "ansx_profile_reset", "ansx_profile_get",
-    "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2",
+    "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div",
 ]
 
 
@@ -118,6 +118,8 @@ def lib():
     L.ansx_host_log2.argtypes = [C.c_double]
     L.ansx_selftest_log2.restype = C.c_int
     L.ansx_selftest_log2.argtypes = [vp, vp, vp, sz]
+    L.ansx_selftest_div.restype = C.c_int
+    L.ansx_selftest_div.argtypes = [vp, vp, vp, vp, sz]
     _lib = L
     return L
 

@@ -491,6 +491,12 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     return ANSX_OK;
 }
 
+__global__ void k_selftest_div(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ansx_div_int31(a[i], b[i]);
+}
+
 __global__ void k_selftest_log2(const double* __restrict__ in, double* __restrict__ out, u64 n)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -870,6 +876,24 @@ int ansx_selftest_log2(ansx_ctx* c, const double* in, double* out, size_t n)
     HIPCHK(c, hipMemcpyAsync(c->stage_in.p, in, n * 8, hipMemcpyHostToDevice, s));
     LAUNCH(c, "k_selftest_log2", k_selftest_log2, (n + 255) / 256, 256, 0, s, (const double*)c->stage_in.p,
         (double*)c->stage_out.p, (u64)n);
+    HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return ANSX_OK;
+}
+
+int ansx_selftest_div(ansx_ctx* c, const double* a, const double* b, double* out, size_t n)
+{
+    if (!c || !a || !b || !out || n == 0) return ANSX_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->stage_in, 2 * n * 8))) return rc;
+    if ((rc = ensure(c, c->stage_out, n * 8))) return rc;
+    hipStream_t s = c->stream;
+    double* da = (double*)c->stage_in.p;
+    HIPCHK(c, hipMemcpyAsync(da, a, n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(da + n, b, n * 8, hipMemcpyHostToDevice, s));
+    LAUNCH(c, "k_selftest_div", k_selftest_div, (n + 255) / 256, 256, 0, s, (const double*)da,
+        (const double*)(da + n), (double*)c->stage_out.p, (u64)n);
     HIPCHK(c, hipMemcpyAsync(out, c->stage_out.p, n * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return ANSX_OK;

@@ -157,6 +157,32 @@ ANSX_HD double ansx_log2_portable(double x)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded a / b for integer-valued doubles 0 <= a, 0 < b, both < 2^31 -- the only
+// divisions of the normaliser (M_rem / fs_rem, ans_util.hpp:83; count / n, util.hpp:276,291).
+// hipcc expands an IEEE f64 division into v_div_scale x2, v_rcp, ~6 fma, v_div_fmas, v_div_fixup,
+// several of them slow-rate; for these operands the Markstein sequence below gives the same bits:
+//   y  = 1/b to ~1 ulp (hardware seed 2^-24.5, two Newton steps)
+//   q  = RN(a*y);  r = a - q*b (exact in one fma: q is within 2 ulp of a/b);  q' = RN(q + r*y)
+// q + r*y differs from a/b by |r|*|y - 1/b| <= 2^-105 relative, while a/b -- a ratio of integers
+// below 2^31 -- is either representable or at least 2^-84 (relative) away from every rounding
+// midpoint (b*m - a is a non-zero multiple of the midpoint's last place), so the final rounding
+// cannot differ from the IEEE one.  Checked against true division on the device (ansx_selftest_div).
+// Host builds (tests) use the plain operator.
+ANSX_HD double ansx_div_int31(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y0 = __builtin_amdgcn_rcp(b);
+    const double y1 = __builtin_fma(__builtin_fma(-b, y0, 1.0), y0, y0);
+    const double y2 = __builtin_fma(__builtin_fma(-b, y1, 1.0), y1, y1);
+    const double q = a * y2;
+    const double r = __builtin_fma(-q, b, a);
+    return __builtin_fma(r, y2, q);
+#else
+    return a / b;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Quad (4-lane) cross-lane helpers on DPP quad_perm — the renorm byte-emit compaction of
 // ans_fold.hpp:100-112 / :216-228: 4 interleaved states share one byte cursor.
 // ---------------------------------------------------------------------------------------------

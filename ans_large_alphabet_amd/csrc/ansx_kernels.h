@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
             h[s] = fr;
             double t = 0.0;
             if (fr) {
-                const double p = (double)fr / nd;
+                const double p = ansx_div_int31((double)fr, nd);
                 t = p * ansx_log2_portable(p);
             }
             if (sum_here) lds_term[s] = t;
@@ -452,22 +452,31 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     u32 maxS = 0;
     const u32 sigma = B.sigma;
     bool stop = false;
-    // rows are 16-byte aligned and NSP (>= sigma rounded up to 8) entries long
-    uint4 fa = *(const uint4*)(F), fb = *(const uint4*)(F + 4), sy = *(const uint4*)(Sy);
-    for (u32 j0 = 0; j0 < sigma && !stop; j0 += 8) {
-        const u32 fr8[8] = { fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w };
-        const u32 sy8[8] = { sy.x & 0xFFFFu, sy.x >> 16, sy.y & 0xFFFFu, sy.y >> 16,
-            sy.z & 0xFFFFu, sy.z >> 16, sy.w & 0xFFFFu, sy.w >> 16 };
-        if (j0 + 8 < sigma) {  // next chunk in flight while this one is consumed
-            fa = *(const uint4*)(F + j0 + 8);
-            fb = *(const uint4*)(F + j0 + 12);
-            sy = *(const uint4*)(Sy + j0 + 8);
-        }
+    // rows are 16-byte aligned and NSP (>= sigma rounded up to 8) entries long.  Chunks of 8
+    // symbols; the loads run TWO chunks ahead of the serial recurrence (three register buffers, loop
+    // unrolled by three so nothing is copied): one chunk of lead (~1000 cycles of divisions) does
+    // not cover a global load, and the lane then stalls once per chunk.
+    struct chunk {
+        uint4 fa, fb, sy;
+    };
+    const u32 lastc = NSP - 8;
+    auto load_chunk = [&](u32 j0) -> chunk {
+        j0 = j0 < lastc ? j0 : lastc;  // prefetches past the row's end are clamped into it
+        chunk c;
+        c.fa = *(const uint4*)(F + j0);
+        c.fb = *(const uint4*)(F + j0 + 4);
+        c.sy = *(const uint4*)(Sy + j0);
+        return c;
+    };
+    auto run_chunk = [&](const chunk& c, u32 j0) {
+        const u32 fr8[8] = { c.fa.x, c.fa.y, c.fa.z, c.fa.w, c.fb.x, c.fb.y, c.fb.z, c.fb.w };
+        const u32 sy8[8] = { c.sy.x & 0xFFFFu, c.sy.x >> 16, c.sy.y & 0xFFFFu, c.sy.y >> 16,
+            c.sy.z & 0xFFFFu, c.sy.z >> 16, c.sy.w & 0xFFFFu, c.sy.w >> 16 };
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (!stop && j0 + u < sigma) {
                 const double frd = (double)fr8[u];
-                double aratio = Md / fsd;
+                double aratio = ansx_div_int31(Md, fsd);
                 double v = aratio * frd;
                 v = 0.5 + v;
                 u32 sc = (u32)v;
@@ -479,6 +488,15 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
                 if (Md < 0.0) stop = true;  // ans_util.hpp:90-91
             }
         }
+    };
+    chunk c0 = load_chunk(0), c1 = load_chunk(8), c2;
+    for (u32 j0 = 0; j0 < sigma && !stop; j0 += 24) {
+        c2 = load_chunk(j0 + 16);
+        run_chunk(c0, j0);
+        c0 = load_chunk(j0 + 24);
+        run_chunk(c1, j0 + 8);
+        c1 = load_chunk(j0 + 32);
+        run_chunk(c2, j0 + 16);
     }
     const u32 ok = (Md == 0.0) ? 1u : 0u;
     meta[0] = ok;
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
-            const double p = valid ? (double)h8[u] / nd : 0.0;
+            const double p = valid ? ansx_div_int31((double)h8[u], nd) : 0.0;
             const double lg = ansx_log2_stage2(le[u].e - (int)sh, le[u].y, le[u].ylo);
             tm[u] = p * (valid ? lg : 0.0);  // absent: p * log2(1) = +0.0
         }

@@ -142,6 +142,9 @@ double ansx_host_log2(double x);
 /* The same function evaluated on the DEVICE for n inputs (host arrays): the normaliser relies on
  * host and device results being bit-identical. */
 int ansx_selftest_log2(ansx_ctx* ctx, const double* in, double* out, size_t n);
+/* The normaliser's division helper (exact for integer-valued operands below 2^31, see
+ * csrc/ansx_dev.h) evaluated on the device: out[i] = a[i] / b[i], to be compared with IEEE division. */
+int ansx_selftest_div(ansx_ctx* ctx, const double* a, const double* b, double* out, size_t n);
 
 #ifdef __cplusplus
 }

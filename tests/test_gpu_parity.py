@@ -227,6 +227,31 @@ def test_device_log2_bit_identical_to_host(A, ctx):
     assert rel[libm != 0].max() <= 2.3e-16  # within 1 ulp of glibc
 
 
+def test_device_division_helper_is_ieee_exact(A, ctx):
+    """The normaliser divides integer-valued doubles below 2^31 (M_rem / fs_rem, count / n) with a
+    reciprocal-based sequence instead of the compiler's IEEE expansion; it must round identically
+    (proof sketch in csrc/ansx_dev.h).  Random pairs, pairs that make exact quotients, near-ties."""
+    rng = np.random.default_rng(11)
+    a = [rng.integers(0, 1 << 31, size=400000), rng.integers(0, 1 << 16, size=200000),
+         rng.integers(0, 1 << 31, size=200000)]
+    b = [rng.integers(1, 1 << 31, size=400000), rng.integers(1, 1 << 31, size=200000),
+         rng.integers(1, 1 << 12, size=200000)]
+    q = rng.integers(0, 1 << 15, size=100000)
+    d = rng.integers(1, 1 << 16, size=100000)
+    a.append(q * d)                      # exact quotients
+    b.append(d)
+    a.append(np.array([0, 1, (1 << 31) - 1, (1 << 31) - 1, 1, 3, (1 << 31) - 2, 16384, 12345678]))
+    b.append(np.array([1, (1 << 31) - 1, (1 << 31) - 1, 1, 3, (1 << 31) - 1, (1 << 31) - 1, 3, 7]))
+    a = np.concatenate(a).astype(np.float64)
+    b = np.concatenate(b).astype(np.float64)
+    out = np.zeros_like(a)
+    st = A.lib().ansx_selftest_div(ctx.handle, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    assert st == 0
+    want = a / b
+    bad = np.nonzero(out.view(np.uint64) != want.view(np.uint64))[0]
+    assert bad.size == 0, (bad[:5], a[bad[:5]], b[bad[:5]], out[bad[:5]], want[bad[:5]])
+
+
 def test_device_log2_matches_host_portable_log2(A, ctx):
     """The normaliser's log2 must be the same function on host and device; exercised indirectly:
     blocks whose XH lands near the threshold would flip otherwise.  Direct check through a

@@ -312,7 +312,8 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
             0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
-            (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)hterm, (const ansx_log2_ent*)c->log2lut.p);
+            (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)hterm, (const ansx_log2_ent*)c->log2lut.p,
+            g.block_ints <= 65535u ? 1u : 0u);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
             (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);

@@ -405,13 +405,14 @@ __global__ void k_build_log2_lut(ansx_log2_ent* __restrict__ lut)
 __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u32* __restrict__ sortF, const u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk, u16* __restrict__ attS, u32* __restrict__ attMeta,
-    const double* __restrict__ hterm, const ansx_log2_ent* __restrict__ l2lut)
+    const double* __restrict__ hterm, const ansx_log2_ent* __restrict__ l2lut, u32 stage_ok)
 {
+    __shared__ u32 scale_stage[256 / ANSX_ATTEMPTS][256];  // 32 KB: 256 (freq | sym << 16) words per block
     const u32 gid = blockIdx.x * 256 + threadIdx.x;
     const u32 b = gid / ANSX_ATTEMPTS, t = gid % ANSX_ATTEMPTS;
     if (b >= g.nblocks) return;
     const ansx_blk B = blk[b];
-    if (B.resolved) return;
+    if (B.resolved) return;  // (all ANSX_ATTEMPTS lanes of a block leave together)
     if (hterm != nullptr && batch == 0 && t == 0) {
         // entropy H = -sum p*log2(p), left to right in index order (util.hpp:271-282); the terms
         // come from k_fold_hist.  One lane per block, 8 blocks per wave in parallel.
@@ -434,14 +435,15 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     const u32 T = batch * ANSX_ATTEMPTS + t;
     const u32 sh = B.m0_log2 + T;
     u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;
-    if (sh > 31) {  // frame sizes beyond 2^31 are unreachable for valid inputs
+    const bool dead = sh > 31;  // frame sizes beyond 2^31 are unreachable for valid inputs
+    if (dead) {
         meta[0] = 0;
         meta[1] = 0;
-        return;
+        if (!stage_ok) return;  // (with staging the lane still helps to load its block's symbols)
     }
     // M and freq_sum are integers < 2^53: carried as doubles (exact), which keeps the
     // int64/uint64 -> double conversions of ans_util.hpp:83 out of the dependency chain
-    double Md = (double)((i64)1 << sh);
+    double Md = (double)((i64)1 << (dead ? 0u : sh));
     double fsd = (double)B.n;
     const u32* F = sortF + (u64)b * NSP;
     const u16* Sy = sortSym + (u64)b * NSP;
@@ -451,52 +453,84 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + t;
     u32 maxS = 0;
     const u32 sigma = B.sigma;
-    bool stop = false;
-    // rows are 16-byte aligned and NSP (>= sigma rounded up to 8) entries long.  Chunks of 8
-    // symbols; the loads run TWO chunks ahead of the serial recurrence (three register buffers, loop
-    // unrolled by three so nothing is copied): one chunk of lead (~1000 cycles of divisions) does
-    // not cover a global load, and the lane then stalls once per chunk.
-    struct chunk {
-        uint4 fa, fb, sy;
+    bool stop = dead;
+    auto scale_one = [&](u32 fr, u32 sy) {  // one step of scale_freqs (ans_util.hpp:80-92)
+        const double frd = (double)fr;
+        double aratio = ansx_div_int31(Md, fsd);
+        double v = aratio * frd;
+        v = 0.5 + v;
+        u32 sc = (u32)v;
+        if (sc == 0) sc = 1;
+        S[sy * ANSX_ATTEMPTS] = (u16)(sc > 65535u ? 65535u : sc);
+        maxS = sc > maxS ? sc : maxS;
+        Md = Md - (double)sc;
+        fsd = fsd - frd;
+        if (Md < 0.0) stop = true;  // ans_util.hpp:90-91
     };
-    const u32 lastc = NSP - 8;
-    auto load_chunk = [&](u32 j0) -> chunk {
-        j0 = j0 < lastc ? j0 : lastc;  // prefetches past the row's end are clamped into it
-        chunk c;
-        c.fa = *(const uint4*)(F + j0);
-        c.fb = *(const uint4*)(F + j0 + 4);
-        c.sy = *(const uint4*)(Sy + j0);
-        return c;
-    };
-    auto run_chunk = [&](const chunk& c, u32 j0) {
-        const u32 fr8[8] = { c.fa.x, c.fa.y, c.fa.z, c.fa.w, c.fb.x, c.fb.y, c.fb.z, c.fb.w };
-        const u32 sy8[8] = { c.sy.x & 0xFFFFu, c.sy.x >> 16, c.sy.y & 0xFFFFu, c.sy.y >> 16,
-            c.sy.z & 0xFFFFu, c.sy.z >> 16, c.sy.w & 0xFFFFu, c.sy.w >> 16 };
+    if (stage_ok) {
+        // Blocks of at most 65535 ints (frequencies fit 16 bits): the (frequency, symbol) pairs are
+        // staged 256 at a time in LDS by the block's 8 lanes, packed into one word.  The recurrence
+        // stores one S per symbol, and a global load consumed behind those stores waits for them
+        // (in-order vmcnt): per 8-symbol register chunk that was half of the wave's cycles; per
+        // 256-symbol stage it is 2-3 drains per block.
+        u32* st = &scale_stage[threadIdx.x / ANSX_ATTEMPTS][0];
+        for (u32 c0 = 0; c0 < sigma; c0 += 256) {
+            wave_lds_sync();  // previous stage fully consumed by the block's lanes (same wave)
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (!stop && j0 + u < sigma) {
-                const double frd = (double)fr8[u];
-                double aratio = ansx_div_int31(Md, fsd);
-                double v = aratio * frd;
-                v = 0.5 + v;
-                u32 sc = (u32)v;
-                if (sc == 0) sc = 1;
-                S[sy8[u] * ANSX_ATTEMPTS] = (u16)(sc > 65535u ? 65535u : sc);
-                maxS = sc > maxS ? sc : maxS;
-                Md = Md - (double)sc;
-                fsd = fsd - frd;
-                if (Md < 0.0) stop = true;  // ans_util.hpp:90-91
+            for (u32 k = 0; k < 256 / (4 * ANSX_ATTEMPTS); k++) {
+                u32 j = c0 + 4 * t + 4 * ANSX_ATTEMPTS * k;
+                j = j < NSP - 4 ? j : NSP - 4;  // rows are NSP entries long
+                const uint4 f4 = *(const uint4*)(F + j);
+                const uint2 s2 = *(const uint2*)(Sy + j);
+                const uint4 pk = make_uint4((f4.x & 0xFFFFu) | (s2.x << 16), (f4.y & 0xFFFFu) | (s2.x & 0xFFFF0000u),
+                    (f4.z & 0xFFFFu) | (s2.y << 16), (f4.w & 0xFFFFu) | (s2.y & 0xFFFF0000u));
+                *(uint4*)(st + 4 * t + 4 * ANSX_ATTEMPTS * k) = pk;
             }
+            wave_lds_sync();
+            const u32 lim = sigma - c0 < 256 ? sigma - c0 : 256;
+            for (u32 j0 = 0; j0 < lim && !stop; j0 += 8) {
+                u32 e8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) e8[u] = st[j0 + u];  // 256-entry rows: no overrun
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (!stop && j0 + u < lim) scale_one(e8[u] & 0xFFFFu, e8[u] >> 16);
+            }
+            // (a lane that has stopped keeps staging: the other lanes of its block need the data)
         }
-    };
-    chunk c0 = load_chunk(0), c1 = load_chunk(8), c2;
-    for (u32 j0 = 0; j0 < sigma && !stop; j0 += 24) {
-        c2 = load_chunk(j0 + 16);
-        run_chunk(c0, j0);
-        c0 = load_chunk(j0 + 24);
-        run_chunk(c1, j0 + 8);
-        c1 = load_chunk(j0 + 32);
-        run_chunk(c2, j0 + 16);
+        if (dead) return;
+    } else {
+        // rows are 16-byte aligned and NSP (>= sigma rounded up to 8) entries long: register chunks
+        // of 8 symbols, loaded two chunks ahead of the recurrence
+        struct chunk {
+            uint4 fa, fb, sy;
+        };
+        const u32 lastc = NSP - 8;
+        auto load_chunk = [&](u32 j0) -> chunk {
+            j0 = j0 < lastc ? j0 : lastc;  // prefetches past the row's end are clamped into it
+            chunk c;
+            c.fa = *(const uint4*)(F + j0);
+            c.fb = *(const uint4*)(F + j0 + 4);
+            c.sy = *(const uint4*)(Sy + j0);
+            return c;
+        };
+        auto run_chunk = [&](const chunk& c, u32 j0) {
+            const u32 fr8[8] = { c.fa.x, c.fa.y, c.fa.z, c.fa.w, c.fb.x, c.fb.y, c.fb.z, c.fb.w };
+            const u32 sy8[8] = { c.sy.x & 0xFFFFu, c.sy.x >> 16, c.sy.y & 0xFFFFu, c.sy.y >> 16,
+                c.sy.z & 0xFFFFu, c.sy.z >> 16, c.sy.w & 0xFFFFu, c.sy.w >> 16 };
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (!stop && j0 + u < sigma) scale_one(fr8[u], sy8[u]);
+        };
+        chunk c0 = load_chunk(0), c1 = load_chunk(8), c2;
+        for (u32 j0 = 0; j0 < sigma && !stop; j0 += 24) {
+            c2 = load_chunk(j0 + 16);
+            run_chunk(c0, j0);
+            c0 = load_chunk(j0 + 24);
+            run_chunk(c1, j0 + 8);
+            c1 = load_chunk(j0 + 32);
+            run_chunk(c2, j0 + 16);
+        }
     }
     const u32 ok = (Md == 0.0) ? 1u : 0u;
     meta[0] = ok;

@@ -1726,7 +1726,10 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
 
 // 8 stream bytes ending at byte offset `end` (exclusive): from the LDS-staged copy (aligned
 // words + v_alignbyte) or straight from global memory (one unaligned 8-byte load)
-#define ANSX_RING_BYTES 512
+// per-quad stream ring of the block decoder: ANSX_RING_CHK steps per refill check, 32 bytes per lane
+// and step of check interval per refill (>= the 28 bytes a quad can consume per step)
+#define ANSX_RING_CHK 4
+#define ANSX_RING_BYTES (128 * ANSX_RING_CHK)
 template <int MODE>
 __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end)
 {
@@ -1739,12 +1742,15 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
         const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
         return ((u64)hi << 32) | lo;
     } else if (MODE == 2) {
-        // lds_stream = this quad's ring: stream byte s lives at ring byte s & (ANSX_RING_BYTES-1)
-        const u32 a = (u32)(end - 8);
+        // lds_stream = this quad's ring, 512-byte aligned in LDS: stream byte s lives at ring byte
+        // s & 511, so each of the three word addresses is one bit-field insert into the ring's base
+        typedef __attribute__((address_space(3))) const u32 lds_cu32;
+        const u32 rb = (u32)(size_t)(__attribute__((address_space(3))) const void*)lds_stream;
+        const u32 a = (u32)end;
+        const u32 m = ANSX_RING_BYTES - 4;  // word-aligned offset bits
+        const u32 a0 = ((a - 8) & m) | (rb & ~m), a1 = ((a - 4) & m) | (rb & ~m), a2 = (a & m) | (rb & ~m);
+        const u32 w0 = *(lds_cu32*)(size_t)a0, w1 = *(lds_cu32*)(size_t)a1, w2 = *(lds_cu32*)(size_t)a2;
         const u32 sh = a & 3;
-        const u32 i0 = (a >> 2) & (ANSX_RING_BYTES / 4 - 1);
-        const u32 i1 = (i0 + 1) & (ANSX_RING_BYTES / 4 - 1), i2 = (i0 + 2) & (ANSX_RING_BYTES / 4 - 1);
-        const u32 w0 = lds_stream[i0], w1 = lds_stream[i1], w2 = lds_stream[i2];
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
         const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
         return ((u64)hi << 32) | lo;
@@ -1824,7 +1830,11 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     const u32 slot = (u32)st & mask;
     u32 fr, base, pv;
     lut.get(slot, fr, base, pv);
-    u64 ns_ = (u64)fr * (st >> logM) + (u64)(slot - base);  // ans_fold.hpp:218-220
+    // ans_fold.hpp:218-220: fr * (st >> logM) + (slot - base).  st < 2^52 for frames up to 2^16, so
+    // the high word of the quotient is small: one 32x32->64 mad plus a 24-bit multiply-add
+    const u64 qs = st >> logM;
+    u64 ns_ = (u64)fr * (u32)qs + (u64)(slot - base);
+    ns_ += (u64)__umul24(fr, (u32)(qs >> 32)) << 32;
     const bool rn = active && (ns_ < Lb);
     const u32 k = pv >> 30;
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
@@ -1920,22 +1930,25 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
 
 // ---- per-quad stream ring ------------------------------------------------------------------
 // Instead of the whole block stream (~20 KB at the defaults, which caps a CU at 5 blocks in
-// flight), every quad keeps a 512-byte window of ITS segment's bytes in LDS; stream byte s lives
-// at ring byte s & 511.  The cursor p walks down at most 28 bytes per step and a step reads down
-// to p - 32.  Every 4 steps ("check"): the 128 bytes requested at the previous check are written
-// into the ring (lo -= 128), and if less than 368 bytes remain below p another 128 are requested
-// (two 16-byte buffer loads per lane; a lane with nothing to fetch gets an out-of-range offset).
-// Invariant: p - lo >= 256 after every landing, so the 4 steps of an interval (<= 112 bytes) never
-// leave the window, and the window (< 496 bytes before a landing of 128 onto consumed bytes) fits.
+// flight), every quad keeps a window of RB = ANSX_RING_BYTES bytes of ITS segment in LDS; stream
+// byte s lives at ring byte s & (RB-1).  The cursor p walks down at most 28 bytes per step and a
+// step reads down to p - 32.  Every CHK = ANSX_RING_CHK steps ("check") the R = 32*CHK bytes
+// requested at the previous check are written into the ring (lo -= R) and, if fewer than T bytes
+// remain below p, another R are requested (R/64 16-byte buffer loads per lane; a lane with
+// nothing to fetch gets an out-of-range offset).  With c = 28*CHK the most an interval consumes:
+//   L = 32 + c   bytes must remain below p when an interval starts
+//   T = RB - R - 16 >= L + c : after a landing p - lo >= L always (requested: >= L - c + R, not
+//   requested: >= T - c), and before a landing p - lo < T, so the R new bytes replace consumed ones
+//   and the window [lo, p + 4) never exceeds RB.
 // The loads are inline asm, invisible to hipcc's waitcnt pass, and are consumed behind
-// s_waitcnt vmcnt(4): vmcnt is in-order and exactly the interval's 4 output stores are younger,
-// so the wait never touches them (letting the compiler wait for these loads costs a drain of the
-// output stores per refill -- the reason an earlier ring attempt was slower than whole-stream
-// staging).  Used when every segment of the block has the same length (all full blocks).
+// s_waitcnt vmcnt(CHK): vmcnt is in-order and exactly the interval's CHK output stores are
+// younger, so the wait never touches them (letting the compiler wait for these loads costs a
+// drain of the output stores per refill -- the reason an earlier ring attempt was slower than
+// whole-stream staging).  Used when every segment of the block has the same length.
 typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
 struct dec_ring_desc {
     ansx_u32x4 rsrc;  // buffer descriptor over [stream - backoff, stream + sbytes + slack) inside the container
-    int backoff;  // stream offset s is at buffer offset s + backoff
+    int backoff;      // stream offset s is at buffer offset s + backoff
 };
 __device__ __forceinline__ ansx_u32x4 ring_load16(const dec_ring_desc& D, int s, bool want)
 {
@@ -1951,14 +1964,21 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
     u32 logM, const LUT& lut, const u8* __restrict__ stream, u32* rings, const dec_ring_desc& D,
     const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o)
 {
+    constexpr int RB = ANSX_RING_BYTES, CHK = ANSX_RING_CHK;
+    constexpr int R = 32 * CHK;        // bytes per refill, 8 * CHK per lane
+    constexpr int NP = CHK / 2;        // 16-byte pieces per lane and refill
+    constexpr int T = RB - R - 16;     // request threshold
+    static_assert(CHK == 2 || CHK == 4, "lane pieces are 16 or 32 bytes");
+    static_assert(T >= 32 + 2 * 28 * CHK, "ring too small for the worst-case consumption");
     const u32 nseg = g.block_ints / g.ckpt;  // uniform segments (checked by the caller)
     const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
     const dec_quad_const qc = { 8 * ql, (1u << (8 * ql)) - 1u };
     const u64 Lb = (u64)16 << logM;
     const u32 mask = (1u << logM) - 1;
-    u32* ring = rings + quad * (ANSX_RING_BYTES / 4);
+    u32* ring = rings + quad * (RB / 4);
     u8* ring8 = (u8*)ring;
     const u32 steps = g.ckpt >> 2;
+    const int lane_off = (R / 4) * (int)ql;  // this lane's share of a refill
     for (u32 seg = quad; seg < nseg; seg += nq) {
         u64 st;
         int p;
@@ -1972,50 +1992,51 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
             p = (int)(po < sbytes ? po : sbytes);
         }
         u32 q = (u32)(-p);
-        // initial window [lo, lo + 512), lo = (p - 384) rounded down to 32 (a lane's two 16-byte
-        // pieces of a refill then never straddle the ring's end): 8 pieces per lane
-        int lo = (p - 384) & ~31;
+        // initial window [lo, lo + RB) with p - lo in [T, T + R/4): RB/64 pieces per lane.  lo is a
+        // multiple of the lane share, so a lane's pieces never straddle the ring's end.
+        int lo = (p - T) & ~(R / 4 - 1);
         {
-            ansx_u32x4 r[8];
+            ansx_u32x4 r[RB / 64];
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = ring_load16(D, lo + 128 * (int)ql + 16 * j, true);
+            for (int j = 0; j < RB / 64; j++) r[j] = ring_load16(D, lo + (RB / 4) * (int)ql + 16 * j, true);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                // keep the data dependence on the asm loads visible after the wait
-                asm volatile("" : "+v"(r[j]));
-                *(ansx_u32x4*)(ring8 + ((u32)(lo + 128 * (int)ql + 16 * j) & (ANSX_RING_BYTES - 1))) = r[j];
+            for (int j = 0; j < RB / 64; j++) {
+                asm volatile("" : "+v"(r[j]));  // keep the dependence on the asm loads behind the wait
+                *(ansx_u32x4*)(ring8 + ((u32)(lo + (RB / 4) * (int)ql + 16 * j) & (RB - 1))) = r[j];
             }
         }
         u32* op = o + seg * g.ckpt + ql;
         bool pending = false;
-        ansx_u32x4 r0 = { 0u, 0u, 0u, 0u }, r1 = r0;
-        u32 i = 0;
-        for (; i + 4 <= steps; i += 4) {
-            // ---- check: land the previous request, decide the next one
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1)::"memory");
-            if (pending) {
-                lo -= 128;
-                const u32 d0 = (u32)(lo + 32 * (int)ql) & (ANSX_RING_BYTES - 1);
-                *(ansx_u32x4*)(ring8 + d0) = r0;
-                *(ansx_u32x4*)(ring8 + d0 + 16) = r1;  // 32-byte aligned pair: no wrap inside
-            }
-            const int cur = -(int)q;
-            pending = (cur - lo) < 368;
-            r0 = ring_load16(D, lo - 128 + 32 * (int)ql, pending);
-            r1 = ring_load16(D, lo - 128 + 32 * (int)ql + 16, pending);
+        ansx_u32x4 rr[NP];
 #pragma unroll
-            for (u32 u = 0; u < 4; u++)
+        for (int j = 0; j < NP; j++) rr[j] = ansx_u32x4{ 0u, 0u, 0u, 0u };
+        auto land = [&]() {
+            if (pending) {
+                lo -= R;
+                const u32 d0 = (u32)(lo + lane_off) & (RB - 1);
+#pragma unroll
+                for (int j = 0; j < NP; j++) *(ansx_u32x4*)(ring8 + d0 + 16 * j) = rr[j];  // aligned share: no wrap inside
+            }
+        };
+        u32 i = 0;
+        for (; i + CHK <= steps; i += CHK) {
+            // ---- check: land the previous request, decide the next one
+            if constexpr (CHK == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
+            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(rr[0])::"memory");
+            land();
+            const int cur = -(int)q;
+            pending = (cur - lo) < T;
+#pragma unroll
+            for (int j = 0; j < NP; j++) rr[j] = ring_load16(D, lo - R + lane_off + 16 * j, pending);
+#pragma unroll
+            for (u32 u = 0; u < (u32)CHK; u++)
                 op[4 * (i + u)] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
         }
-        // leftover steps (ckpt not a multiple of 16): land what is in flight first
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1)::"memory");
-        if (pending) {
-            lo -= 128;
-            const u32 d0 = (u32)(lo + 32 * (int)ql) & (ANSX_RING_BYTES - 1);
-            *(ansx_u32x4*)(ring8 + d0) = r0;
-            *(ansx_u32x4*)(ring8 + d0 + 16) = r1;
-        }
+        // leftover steps (restart interval not a multiple of 4*CHK): land what is in flight first
+        if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0])::"memory");
+        land();
         for (; i < steps; i++) op[4 * i] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
     }
 }
@@ -2167,7 +2188,10 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         if (span > room) span = room;
         const u64 ba = (u64)(uintptr_t)base;
         D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
-        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, lds_stream, D, ckpt_state, ckpt_off, o);
+        // rings start at the next ring-size boundary of the LDS address space (the host adds the slack)
+        const u32 labs = (u32)(size_t)(__attribute__((address_space(3))) void*)lds_stream;
+        u32* rings = lds_stream + ((((labs + (ANSX_RING_BYTES - 1)) & ~(u32)(ANSX_RING_BYTES - 1)) - labs) >> 2);
+        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o);
     } else if (st_lds)
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else

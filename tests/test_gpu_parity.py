@@ -403,6 +403,29 @@ def test_decoder_stream_modes(A, ctx, monkeypatch, kind, f):
                 assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, env)
 
 
+def test_random_geometries_round_trip_and_match_oracle(A, ctx):
+    """Seeded sweep over block sizes / restart intervals / lengths that exercise the geometry-
+    dependent paths: restart intervals that are not a multiple of 16 ints (ring leftover steps),
+    blocks that are / are not a multiple of the interval (ring vs staged decoder), partial last
+    blocks, fewer segments than a wave, one-int tails.  Every block stream and restart point must
+    equal the oracle's and the decoder must return the input."""
+    rng = np.random.default_rng(2024)
+    fams = ["zipf20s1.2", "uniform256", "uniform20", "geom0.01", "sparse_large"]
+    cases = [(4112, 1028, 3 * 4112 + 5), (16448, 1028, 2 * 16448), (8192, 2048, 8192 * 3 + 4095),
+             (4096, 4096, 4096 * 5 + 1), (1024, 256, 1024 * 9 + 3), (20480, 1280, 20480 * 2 + 1281),
+             (16384, 64, 16384 + 70), (2052, 4, 2052 * 2 + 2), (65536, 1024, 65536 + 1000)]
+    for block, ckpt, n in cases:
+        fam = fams[int(rng.integers(0, len(fams)))]
+        kind, f = [(ol.FOLD, 1), (ol.FOLD, 3), (ol.RFOLD, 1), (ol.MSB, 0)][int(rng.integers(0, 4))]
+        data = ol.gen_inputs(fam, n, seed=int(rng.integers(1, 1 << 30)))
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ckpt)
+        cont = codec.encode(data)
+        check_container(A, cont, data, kind, f, block, ckpt)
+        assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, n, fam, kind, f)
+
+
 def test_encoder_table_modes(A, ctx, monkeypatch):
     """Alphabets too large for the LDS-table encoder take the compact-table-from-HBM mode (f64 state,
     branch-free step, hand-counted vmcnt waits); ANSX_ENCODE_GTAB16 forces the older 16-byte-entry

@@ -308,6 +308,11 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     // needs anyway (largest alphabet / frame), so further batches are launched only on demand.
     const u32 nbatch = 24 / ANSX_ATTEMPTS;  // t < 24 (t <= 16 suffices)
     u32 max_logM = 0, max_ns = 0;
+    // consumers of the 16-byte table entries that are certain before the frames are known: the
+    // generic prelude writer (alphabets above 4096 slots) and the integer-state encoder (forced, or
+    // scratch slots too far apart for the f64 encoder's 31-bit buffer offsets)
+    const bool test_fixup = getenv("ANSX_TEST_TABLE16_FIXUP") != nullptr;  // tests: integer-state encoder fed by k_table16_from32
+    const u32 always16 = (!test_fixup && (NSP > 4096 || (u64)scr_stride * 16 >= 0x7FFFFF00ull || getenv("ANSX_ENCODE_GTAB16"))) ? 1u : 0u;
     for (u32 batch = 0; batch < nbatch; batch++) {
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
@@ -316,7 +321,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
             g.block_ints <= 65535u ? 1u : 0u);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
-            (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u);
+            (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u, always16);
         HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         int st0 = flags_to_status(c->h_pin[ANSX_G_ERR]);
@@ -325,6 +330,9 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         max_ns = c->h_pin[ANSX_G_MAXNSYMS];
         if (c->h_pin[ANSX_G_PAD] == 0) break;
     }
+    if (!always16 && (max_logM > 16 || test_fixup))  // mixed call: a frame above 2^16 sends every block to the integer-state encoder
+        LAUNCH(c, "k_table16_from32", k_table16_from32, NB, 256, 0, s, g, NSP, (const ansx_blk*)blk,
+            (const u32*)c->tab32.p, (ansx_enc_entry*)c->table.p);
     // K3
     if (NSP <= 1024 && max_logM <= 16) {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
@@ -349,7 +357,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
     // (its emitted-byte stores go through a buffer descriptor spanning the wave's 16 scratch slots:
     // 31-bit offsets)
-    const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
+    const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull && !test_fixup;
     if (f64_ok && enc_lds <= 40 * 1024) {
         LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,

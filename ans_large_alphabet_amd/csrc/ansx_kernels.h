@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
 __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u16* __restrict__ attS, const u32* __restrict__ attMeta,
     u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
-    u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch)
+    u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch, u32 always16)
 {
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
@@ -650,6 +650,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     // lane = symbol, 64 symbols per pass (coalesced), wave prefix sum, carry between passes
     ansx_enc_entry* tab = table + (u64)b * NSP;
     u32* t32 = tab32 + (u64)b * NSP;
+    // the 16-byte entries (32-bit base/freq + reciprocal) are only read by the integer-state encoder
+    // and the generic prelude writer: frames above 2^16 always get them, other blocks only when the
+    // host already knows such a consumer will run (always16) -- or later through k_table16_from32
+    const bool write16 = always16 || (B->m0_log2 + (u32)chosen) > 16;
     u32 carry = 0;
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
@@ -664,11 +668,13 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         }
         const u32 base = carry + incl - fr;
         if (s < ns) {
-            ansx_enc_entry e;
-            e.base = base;
-            e.freq = fr;
-            e.rcp = fr ? 1.0 / (double)fr : 0.0;
-            tab[s] = e;
+            if (write16) {
+                ansx_enc_entry e;
+                e.base = base;
+                e.freq = fr;
+                e.rcp = fr ? 1.0 / (double)fr : 0.0;
+                tab[s] = e;
+            }
             t32[s] = (base << 16) | fr;  // valid while M <= 65536 (base < 2^16, freq < 65535)
         }
         carry += __shfl(incl, 63);
@@ -683,6 +689,25 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
             atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+    }
+}
+
+// 16-byte table entries for the blocks whose frame is at most 2^16 (k_select_model skipped them),
+// rebuilt from the compact entries.  Only launched in the rare mixed case: some block of the call
+// needs a frame above 2^16, so the integer-state encoder runs for all of them.
+__global__ __launch_bounds__(256) void k_table16_from32(ansx_geo g, u32 NSP, const ansx_blk* __restrict__ blk,
+    const u32* __restrict__ tab32, ansx_enc_entry* __restrict__ table)
+{
+    const u32 b = blockIdx.x;
+    if (blk[b].status || blk[b].logM > 16) return;
+    const u32 ns = blk[b].max_sym + 1;
+    for (u32 s = threadIdx.x; s < ns; s += 256) {
+        const u32 w = tab32[(u64)b * NSP + s];
+        ansx_enc_entry e;
+        e.base = w >> 16;
+        e.freq = w & 0xFFFFu;
+        e.rcp = e.freq ? 1.0 / (double)e.freq : 0.0;
+        table[(u64)b * NSP + s] = e;
     }
 }
 

@@ -10,6 +10,7 @@ import json
 import os
 
 import numpy as np
+import subprocess
 import pytest
 
 import oracle_lib as ol
@@ -424,6 +425,41 @@ def test_random_geometries_round_trip_and_match_oracle(A, ctx):
         cont = codec.encode(data)
         check_container(A, cont, data, kind, f, block, ckpt)
         assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, n, fam, kind, f)
+
+
+def test_harnesses_run_and_stream_bits_equal_the_reference(A, ctx, tmp_path):
+    """tools/table_effectiveness --stream writes exactly the reference's streams, so its bits/int
+    column must equal 8 * len(reference stream) / n (the oracle stands in for the reference: it is
+    pinned byte-identical to it); tools/table_efficiency must run and verify its round trips."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = os.path.join(root, "ans_large_alphabet_amd", "tools")
+    subprocess.run(["make", "-C", tools], check=True, capture_output=True)
+    files = {"a_uniform.u32": ol.gen_inputs("uniform256", 20000, seed=1),
+             "b_zipf.u32": ol.gen_inputs("zipf20s1.2", 30001, seed=2)}
+    for name, arr in files.items():
+        arr.astype(np.uint32).tofile(str(tmp_path / name))
+    out = subprocess.run([os.path.join(tools, "table_effectiveness.x"), "-i", str(tmp_path), "--stream"],
+                         check=True, capture_output=True, text=True).stdout
+    rows = {}
+    cur = None
+    for line in out.splitlines():
+        m = re.match(r"^(ANS\S+)\s+&$", line)
+        if m:
+            cur = m.group(1)
+            rows[cur] = []
+        elif cur and re.search(r"\d+\.\d{4}", line):
+            rows[cur].append(float(re.search(r"(\d+\.\d{4})", line).group(1)))
+    for name, kind, f in (("ANSfold-1", ol.FOLD, 1), ("ANSfold-5", ol.FOLD, 5), ("ANSrfold-3", ol.RFOLD, 3), ("ANSmsb", ol.MSB, 0)):
+        want = []
+        for key in sorted(files):
+            data = files[key].astype(np.uint32)
+            stream = ol.oracle_encode(kind, f, data)[0]
+            want.append(round(8.0 * stream.size / data.size, 4))
+        assert rows[name] == pytest.approx(want, abs=1.01e-4), (name, rows[name], want)
+    eff = subprocess.run([os.path.join(tools, "table_efficiency.x"), "-i", str(tmp_path), "--bits"],
+                         check=True, capture_output=True, text=True).stdout
+    assert "\\method{ANSfold-1}" in eff and "\\method{ANSrfold-5}" in eff and "bits/int" in eff
 
 
 def test_encoder_table_modes(A, ctx, monkeypatch):

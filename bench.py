@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64 * (1 << 20))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--gather-root", default="rotate", choices=["rotate", "fixed"],
+                    help="N > 1: root of the per-step container gather: rank k mod N of step k (default; "
+                         "spreads the traffic over all xGMI links) or always rank 0")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N > 1 control-flow rehearsal on ONE GPU: gloo backend, every rank on cuda:0, "
                          "containers gathered through host copies (not a measurement)")
@@ -202,37 +205,63 @@ def main():
     else:
         raise SystemExit("unknown --dist")
     cap = min(codec.bound(n), 8 * n + (64 << 20))
-    # N > 1: two container buffers, so that the gather of step k (RCCL send/recv on its own stream)
-    # overlaps this rank's decode of step k AND its encode of step k+1; a buffer is reused only
-    # after the transfer that reads it has been waited for
-    outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
+    # N > 1.  Every step ends with the rank containers concatenated on ONE GPU (RCCL send/recv: each
+    # sender uses its direct xGMI link to the root).  A rank's container is ~0.29 GB, i.e. several ms
+    # on one link -- longer than the step's compute -- so (1) the transfer of step k overlaps the
+    # decode of step k and the following encodes (DEPTH container buffers; a buffer is reused only
+    # after the transfer that reads it has been waited for), (2) the root rotates (rank k mod N), so
+    # consecutive steps use different links / directions instead of funnelling everything into rank
+    # 0's seven links, and (3) each pipeline slot has its own communicator, because groups issued on
+    # one communicator execute back to back on its stream.
+    rotate = world > 1 and args.gather_root == "rotate"
+    DEPTH = 1 if world == 1 else (min(4, max(2, world)) if rotate else 2)
+    outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(DEPTH)]
     d_out = outs[0]
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
     from ans_large_alphabet_amd import dist as adist
+    import collections
 
-    state = {"k": 0, "pending": [], "keep": None}
+    groups = [None] * DEPTH
+    if dist is not None and rotate:
+        groups = [dist.new_group(ranks=list(range(world))) for _ in range(DEPTH)]
+        # establish every (communicator, root) connection before anything is timed
+        tiny = torch.zeros(64, dtype=torch.uint8, device="cpu" if args.rehearse_gloo else device)
+        for g_ in groups:
+            for d_ in range(world):
+                adist.gather_containers(tiny, 64, dst=d_, group=g_, async_op=False)
+        if not args.rehearse_gloo:
+            torch.cuda.synchronize()
 
-    def drain():
-        for w in state["pending"]:
+    state = {"k": 0}
+    pending = collections.deque()  # (works, receive buffer kept alive) of the steps still in flight
+
+    def drain_one():
+        works, _keep = pending.popleft()
+        for w in works:
             w.wait()
-        state["pending"], state["keep"] = [], None
 
     def step():
-        out = outs[state["k"] % len(outs)]
+        k = state["k"]
         state["k"] += 1
+        slot = k % DEPTH
+        out = outs[slot]
         nb = codec.encode_dev(d_in.data_ptr(), n, out.data_ptr(), cap, stream=stream)
         works, buf = [], None
         if dist is not None:
-            # concatenate the per-GPU containers on rank 0: 8-byte sizes first, then one direct
-            # send per rank (each sender uses its own xGMI link to the root)
             src = out[:nb].cpu() if args.rehearse_gloo else out
-            buf, _sizes, works = adist.gather_containers(src, nb, dst=0, async_op=True)
+            buf, _sizes, works = adist.gather_containers(src, nb, dst=(k % world) if rotate else 0,
+                                                         group=groups[slot], async_op=True)
         codec.decode_dev(out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
-        drain()  # the PREVIOUS step's transfer (it read the other buffer)
-        state["pending"], state["keep"] = works, buf
+        pending.append((works, buf))
+        while len(pending) > DEPTH - 1:  # the next user of a buffer must find its transfer finished
+            drain_one()
         return nb
+
+    def drain():
+        while pending:
+            drain_one()
 
     def sync_all():
         drain()
@@ -304,7 +333,9 @@ def main():
                        "ints_per_gpu": n, "distribution": args.dist, "codec": codec.name(),
                        "block_ints": args.block or A.DEFAULT_BLOCK_INTS,
                        "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
-                       "multi_gpu": "contiguous block ranges per rank + RCCL send/recv gather to rank 0" if world > 1 else "single GPU"},
+                       "multi_gpu": ("contiguous block ranges per rank; per-step RCCL send/recv gather of the rank containers to "
+                                     + ("a root that rotates per step (k mod N), %d transfers in flight on %d communicators" % (DEPTH - 1, DEPTH)
+                                        if rotate else "rank 0, overlapped with the next step")) if world > 1 else "single GPU"},
             "roundtrip_ok": ok, "compressed_bytes_per_int": c_bytes, "bits_per_int": 8 * c_bytes,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "workspace_mb": ctx.workspace_bytes() / 1e6,

@@ -1,14 +1,17 @@
 // ansx device kernels (gfx950).  One block = one independent reference encode() call
 // (SURVEY F1); kernels are organised so that lanes = ANS states:
 //
-//   encode:  K1 k_fold_hist       per-block folded-symbol histogram in LDS        ans_fold.hpp:70-78
-//            K2 k_sort_entropy    (freq,sym) sort + entropy H                     ans_util.hpp:114-124, util.hpp:271-282
-//               k_scale_attempts  one lane per (block, frame size) recurrence      ans_util.hpp:77-95
-//               k_select_model    cross entropy + stop rule + encoder table        ans_util.hpp:127-153, ans_fold.hpp:82-91
-//            K3 k_write_prelude   vbyte + log2 M + parallel interpolative coder    ans_util.hpp:46-63, interp.hpp:28-79
-//            K5 k_encode          quad of lanes per block, 4 interleaved states    ans_fold.hpp:100-120,249-278
+//   encode:  K1 k_fold_hist        per-block folded-symbol histogram (4 LDS copies), entropy terms + H   ans_fold.hpp:70-78, util.hpp:271-282
+//            K2 k_sort_entropy     stable counting sort of (freq, sym)                                    ans_util.hpp:114-124
+//               k_scale_attempts   one lane per (block, frame size): scale_freqs + cross entropy          ans_util.hpp:77-95, util.hpp:284-298
+//               k_select_model     stop rule + compact encoder table                                      ans_util.hpp:127-153, ans_fold.hpp:82-91
+//            K3 k_write_prelude    vbyte + log2 M + parallel interpolative coder                          ans_util.hpp:46-63, interp.hpp:28-79
+//            K5 k_encode<MODE>     quad of lanes per block, 4 interleaved states, branch-free step        ans_fold.hpp:100-120,249-278
 //            K6 k_scan_sizes / k_compact / k_write_header   container assembly
-//   decode:  K8 k_decode          prelude parse + LDS tables + quad per segment    ans_fold.hpp:179-228,283-311
+//   decode:  K7 k_parse_prelude_fast / k_parse_prelude   one lane per block                              ans_util.hpp:25-42, interp.hpp:47-63,81-118
+//            K8 k_decode_rank<RFOLD, RING> (k_decode: slot->symbol fallback)   quad per restart segment   ans_fold.hpp:179-228,283-311
+//   rfold:   ansx_rfold.h (value remap in front of K1, ans_reorder_fold.hpp:70-106)
+// DESIGN.md section 5 describes each kernel and the hardware facts they are built around.
 #pragma once
 
 #include "ansx_dev.h"
@@ -1791,9 +1794,9 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
 //  dec_lut_rank : rank/select form, ~(M/4 + 6 nsyms) bytes instead of 2M + 4 nsyms: a bitmap with
 //                 one bit per slot that starts a symbol, interleaved with the running popcount
 //                 before each 32-bit word; rank(slot) = v_bcnt(word & mask, prefix) - 1 indexes
-//                 compact per-present-symbol entries (base << 16 | freq) and symbol ids.  Still
-//                 two dependent LDS reads per step, but 6 instead of 4 workgroups fit a CU and
-//                 frames up to 2^16 keep their tables (and the staged stream) in LDS.
+//                 compact per-present-symbol entries (base << 16 | freq) and value words.  Still
+//                 two dependent LDS reads per step, but a fraction of the LDS: frames up to 2^16
+//                 keep their tables (and the stream rings / staged stream) in LDS.
 // Both return freq, base and pv = k << 30 | value-without-exception-bytes for the slot's symbol
 // (k = number of exception bytes, ans_fold.hpp:150-175; for ANSrfold with the reorder flag set the
 // value is the remapped one, ans_reorder_fold.hpp:207-219,300-301 -- with flag 0 plain fold,
@@ -2076,11 +2079,12 @@ __device__ __forceinline__ void dec_stage_stream(u32* lds_stream, const u8* __re
     if (tid < 2) lds_stream[nw + 2 + tid] = 0;
 }
 
-// ---- K8: one workgroup per block.  Builds the decoder tables, stages the block's stream in LDS
-// when it fits, then one quad of lanes per segment decodes forward from its restart point.
-// (Measured alternatives on MI355X, 256 Mi ints: no staging 1.56 ms; whole-stream staging 1.38 ms;
-// a 512-byte per-quad ring refilled through registers 1.62 ms -- more occupancy, but every refill
-// waits on the in-order vmcnt behind the outstanding output stores.)
+// ---- K8: one workgroup per block.  Builds the decoder tables, then one quad of lanes per segment
+// decodes forward from its restart point, reading the stream through per-quad LDS rings (RING),
+// a staged copy of the whole block stream, or straight from HBM (partial block / no room).
+// (History on MI355X, 256 Mi ints, with the original slot->symbol tables: no staging 1.56 ms;
+// whole-stream staging 1.38 ms; a ring with compiler-managed waits 1.62 ms -- every refill drained
+// the output stores.  With rank/select tables and the hand-counted vmcnt(4) ring: 0.73 ms.)
 //
 // k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
 // RING: per-quad stream rings instead of the staged stream (stream_cap is then the container size).

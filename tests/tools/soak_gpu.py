@@ -1,0 +1,59 @@
+"""Randomised soak test of the GPU codec (manual tool, not collected by pytest):
+
+    SOAK_SECONDS=420 SOAK_SEED=1 python tests/tools/soak_gpu.py        # on an MI355X box
+
+Random codec / fidelity / block size / restart interval / length, adversarial value distributions
+(3 exception bytes everywhere, two extreme symbols, near-constant, wide uniform, ...).  Every case is
+round-tripped; every third small case also has each block stream compared with the oracle.  The
+hand-counted s_waitcnt vmcnt(N) waits of the encoder / ring decoder are timing sensitive by nature,
+which is what this is for.  Round 1: 99 639 iterations in 420 s, 0 failures.
+"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+torch.zeros(1).cuda()
+import oracle_lib as ol, ans_large_alphabet_amd as A
+ctx = A.Context(0)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
+budget = float(os.environ.get("SOAK_SECONDS", "240"))
+def gen(kind, n):
+    c = rng.integers(0, 9)
+    if c == 0: return rng.integers(1 << 24, 1 << 30, size=n, dtype=np.uint32)            # k = 3 everywhere
+    if c == 1: return rng.integers(0, 2, size=n, dtype=np.uint32) * np.uint32((1 << 30) - 1)   # two symbols, extremes
+    if c == 2: return (rng.zipf(1.1, size=n) % (1 << 28)).astype(np.uint32)
+    if c == 3: return rng.integers(0, 1 << int(rng.integers(1, 30)), size=n, dtype=np.uint32)
+    if c == 4: return np.where(rng.random(n) < 0.999, 7, rng.integers(0, 1 << 30, size=n)).astype(np.uint32)  # near-constant
+    if c == 5: return (np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 26)).astype(np.uint32)
+    if c == 6: return rng.integers(0, 300, size=n, dtype=np.uint32)
+    if c == 7: return rng.geometric(0.001, size=n).astype(np.uint32)
+    return ol.gen_inputs("zipf20s1.2", n, seed=int(rng.integers(1, 1 << 30)))
+blocks = [(16384, 1024), (16384, 256), (4096, 512), (65536, 1024), (8192, 2048), (16448, 1028), (1024, 64), (32768, 4096), (2052, 4), (16384, 16384)]
+t0 = time.time(); it = 0; fails = 0
+while time.time() - t0 < budget:
+    it += 1
+    kind, f = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0)][int(rng.integers(0, 7))]
+    block, ckpt = blocks[int(rng.integers(0, len(blocks)))]
+    n = int(rng.integers(1, 1 << int(rng.integers(4, 22))))
+    data = gen(kind, n)
+    if kind == ol.RFOLD: data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    cls = {ol.FOLD: A.ANSfold, ol.RFOLD: A.ANSrfold}.get(kind)
+    codec = A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt) if kind == ol.MSB else cls(f, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    try:
+        cont = codec.encode(data)
+        out = codec.decode(cont, n)
+        ok = np.array_equal(out, data)
+        if ok and n <= 300000 and it % 3 == 0:   # oracle parity of every block stream (CPU cost)
+            parts = A.parse_container(cont)
+            for b in range(parts["header"].nblocks):
+                exp = ol.oracle_encode(kind, f, data[b * block:(b + 1) * block], ckpt_interval=ckpt)[0]
+                if not np.array_equal(parts["streams"][b], exp): ok = False; break
+    except Exception as e:
+        ok = False; print("EXC", repr(e))
+    if not ok:
+        fails += 1
+        print("FAIL it", it, "kind", kind, "f", f, "block", block, "ckpt", ckpt, "n", n); sys.stdout.flush()
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.save(os.path.join(ROOT, "gpurun_out", "soak_fail_%d.npy" % it), data)
+    if it % 50 == 0: print("it", it, "elapsed %.0f s" % (time.time() - t0), "fails", fails); sys.stdout.flush()
+print("SOAK done: iterations", it, "fails", fails)

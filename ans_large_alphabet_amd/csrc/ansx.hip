@@ -670,7 +670,7 @@ int ansx_init(int device, ansx_ctx** out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ANSX_ERR_NO_DEVICE;  // gfx950-only code object
     ansx_ctx* c = new ansx_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
         delete c;
         return ANSX_ERR_HIP;
     }

@@ -364,8 +364,14 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     for (u32 i = tid; i < nb; i += nt) {
         const u32 v = src[i];
         u32 slot = rf_slot(v);
-        while (keys[slot] != v) slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
-        const u32 r = count_of(slot);
+        // every value was inserted above, so the probe ends at its slot; the bound only matters if
+        // the caller's buffer changes under us (a race on the caller's side must not hang the GPU)
+        u32 probes = 0;
+        while (keys[slot] != v && probes < ANSX_RF_SLOTS) {
+            slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+            probes++;
+        }
+        const u32 r = probes < ANSX_RF_SLOTS ? count_of(slot) : 0xFFFFu;
         dst[i] = (r != 0xFFFFu) ? r : v + T;  // :99-103
     }
     if (tid == 0) blk[b].flag = 1;
@@ -539,7 +545,11 @@ __global__ __launch_bounds__(256) void k_rfg_map(const u32* __restrict__ in, ans
     const u32* K = keys + (u64)b * slots;
     const u32 mask = slots - 1;
     u32 slot = rfg_hash(v, mask);
-    while (K[slot] != v) slot = (slot + 1) & mask;
-    const u32 r = counts[(u64)b * slots + slot];
+    u32 probes = 0;  // bounded for the same reason as in k_rfold_remap_hash
+    while (K[slot] != v && probes < slots) {
+        slot = (slot + 1) & mask;
+        probes++;
+    }
+    const u32 r = probes < slots ? counts[(u64)b * slots + slot] : 0xFFFFFFFFu;
     mapped[gid] = (r != 0xFFFFFFFFu) ? r : v + fold_T(g.f);
 }

@@ -120,7 +120,10 @@ int ansx_decode(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* in, size_t
     uint32_t* out, size_t n, const ansx_opts* opts);
 
 /* Device-pointer entry points: in/out are HBM resident; `stream` is a hipStream_t (NULL = the
- * context's own stream).  They return after the result size / status has been read back. */
+ * context's own stream, an ordinary blocking stream: it orders implicitly against work on the legacy
+ * default stream -- e.g. PyTorch's default stream, whose handle is 0 -- but NOT against other
+ * non-blocking streams; pass the stream the input was produced on if there is one).  They return
+ * after the result size / status has been read back. */
 int ansx_encode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint32_t* d_in, size_t n,
     uint8_t* d_out, size_t out_capacity, size_t* out_bytes, const ansx_opts* opts, void* stream);
 int ansx_decode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* d_in, size_t in_bytes,

@@ -462,6 +462,28 @@ def test_harnesses_run_and_stream_bits_equal_the_reference(A, ctx, tmp_path):
     assert "\\method{ANSfold-1}" in eff and "\\method{ANSrfold-5}" in eff and "bits/int" in eff
 
 
+def test_default_stream_ordering_without_synchronize(A, ctx):
+    """PyTorch's default stream has handle 0, which reaches the C-ABI as NULL = the context's own
+    stream.  That stream must be ordered against the legacy default stream: the input below is still
+    being produced by torch kernels when encode_dev is called, and the output is consumed by torch
+    kernels right after decode_dev, with no explicit synchronisation anywhere."""
+    torch = pytest.importorskip("torch")
+    n = 48 * (1 << 20)
+    codec = codec_for(A, ctx, ol.FOLD, 1)
+    cap = codec.bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(99)
+    for rep in range(4):
+        d_back = torch.zeros(n, dtype=torch.int32, device="cuda")
+        x = torch.randint(0, 1 << 20, (n,), generator=g, device="cuda", dtype=torch.int64)
+        for _ in range(6):                      # keep the default stream busy producing the input
+            x = (x * 6364136223846793005 + 1442695040888963407) & ((1 << 40) - 1)
+        d_in = (x >> 20).to(torch.int32)        # < 2^20
+        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap)       # stream = None
+        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n)
+        assert bool(torch.equal(d_back, d_in)), rep
+
+
 def test_encoder_table_modes(A, ctx, monkeypatch):
     """Alphabets too large for the LDS-table encoder take the compact-table-from-HBM mode (f64 state,
     branch-free step, hand-counted vmcnt waits); ANSX_ENCODE_GTAB16 forces the older 16-byte-entry

@@ -225,14 +225,22 @@ def main():
 
     groups = [None] * DEPTH
     if dist is not None and rotate:
-        groups = [dist.new_group(ranks=list(range(world))) for _ in range(DEPTH)]
-        # establish every (communicator, root) connection before anything is timed
-        tiny = torch.zeros(64, dtype=torch.uint8, device="cpu" if args.rehearse_gloo else device)
-        for g_ in groups:
-            for d_ in range(world):
-                adist.gather_containers(tiny, 64, dst=d_, group=g_, async_op=False)
-        if not args.rehearse_gloo:
-            torch.cuda.synchronize()
+        try:
+            groups = [dist.new_group(ranks=list(range(world))) for _ in range(DEPTH)]
+            # establish every (communicator, root) connection before anything is timed
+            tiny = torch.zeros(64, dtype=torch.uint8, device="cpu" if args.rehearse_gloo else device)
+            for g_ in groups:
+                for d_ in range(world):
+                    adist.gather_containers(tiny, 64, dst=d_, group=g_, async_op=False)
+            if not args.rehearse_gloo:
+                torch.cuda.synchronize()
+        except Exception as exc:  # same code on every rank: a setup failure is symmetric
+            if rank == 0:
+                print("bench.py: rotating-root setup failed (%r); using the fixed root" % (exc,), file=sys.stderr)
+            rotate = False
+            DEPTH = 2
+            outs = outs[:2]
+            groups = [None] * DEPTH
 
     state = {"k": 0}
     pending = collections.deque()  # (works, receive buffer kept alive) of the steps still in flight

@@ -6,7 +6,7 @@ Random codec / fidelity / block size / restart interval / length, adversarial va
 (3 exception bytes everywhere, two extreme symbols, near-constant, wide uniform, ...).  Every case is
 round-tripped; every third small case also has each block stream compared with the oracle.  The
 hand-counted s_waitcnt vmcnt(N) waits of the encoder / ring decoder are timing sensitive by nature,
-which is what this is for.  Round 1: 99 639 iterations in 420 s, 0 failures.
+which is what this is for.  Round 1: 99 639 iterations (seed 1, 420 s) and 122 690 (seed 7, 540 s), 0 failures.
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

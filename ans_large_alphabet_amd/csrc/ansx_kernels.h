@@ -1827,18 +1827,17 @@ struct dec_lut_table {
 };
 struct dec_lut_rank {
     const uint2* bwp;  // {bitmap word, set bits before it}
-    const u32* ent;    // per present symbol: base << 16 | freq
-    const u32* pval;   // per present symbol: k << 30 | value without its exception bytes
+    const uint2* ep;   // per present symbol: {base << 16 | freq, k << 30 | value without its exception bytes}
     __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
     {
         const uint2 wp = bwp[slot >> 5];
         // bits [0, slot & 31] of the word: shift the rest out at the top (the shifter uses the low
         // five bits of ~slot = 31 - (slot & 31))
         const u32 r = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y - 1u;
-        const u32 e = ent[r];
-        pv = pval[r];
-        fr = e & 0xFFFFu;
-        base = e >> 16;
+        const uint2 e = ep[r];  // one 8-byte LDS read
+        pv = e.y;
+        fr = e.x & 0xFFFFu;
+        base = e.x >> 16;
     }
 };
 
@@ -2114,10 +2113,8 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     u32 off = 0;
     uint2* bwp = (uint2*)(smem + off);
     off += (wmax * 8 + 15) & ~15u;
-    u32* ent = (u32*)(smem + off);
-    off += (max_ns * 4 + 15) & ~15u;
-    u32* pval = (u32*)(smem + off);
-    off += (max_ns * 4 + 15) & ~15u;
+    uint2* ep = (uint2*)(smem + off);
+    off += 2 * ((max_ns * 4 + 15) & ~15u);  // (same bytes as the host's 2 x rup(4 max_ns, 16))
     u32* lds_stream = (u32*)(smem + off);
     const u32 W = M >= 32 ? M / 32 : 1;
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
@@ -2156,12 +2153,11 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
             if (pres) {
                 if (base < M && base + fr <= M) {
                     const u32 r = carryP + incP - 1;
-                    ent[r] = (base << 16) | fr;
                     // ANSrfold: the most-frequent values follow the 4-byte flag word
                     // (ans_reorder_fold.hpp:132-154)
                     u32 mfv = 0;
                     if (RFOLD && rflag && s < T) mfv = ld_u32_unaligned(stream + 4 + 4 * (u64)s);
-                    pval[r] = dec_make_pv(f, s, RFOLD && rflag, T, mfv);
+                    ep[r] = make_uint2((base << 16) | fr, dec_make_pv(f, s, RFOLD && rflag, T, mfv));
                     atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
                 } else {
                     bad = 1;
@@ -2202,8 +2198,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     __syncthreads();
     dec_lut_rank lut;
     lut.bwp = bwp;
-    lut.ent = ent;
-    lut.pval = pval;
+    lut.ep = ep;
     u32* o = outp + (u64)b * g.block_ints;
     if (RING && nb == g.block_ints) {  // full block: all segments have g.ckpt ints (host-checked)
         // buffer view of this block's stream with up to 1 KB in front of it (the initial window and

@@ -16,12 +16,13 @@ SINGLE_STREAM = 0xFFFFFFFF
 NO_CHECKPOINTS = 0xFFFFFFFF
 DEFAULT_BLOCK_INTS = 16384
 DEFAULT_CKPT_INTERVAL = 1024
+MAX_FIDELITY = 5
 
 EXPORTS = [
     "ansx_init", "ansx_destroy", "ansx_strerror", "ansx_last_hip_error", "ansx_codec_name",
     "ansx_bound", "ansx_encode", "ansx_decode", "ansx_encode_dev", "ansx_decode_dev",
     "ansx_container_info", "ansx_profile_enable", "ansx_profile_reset", "ansx_profile_get",
-    "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div",
+    "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div", "ansx_debug_set",
 ]
 
 
@@ -114,6 +115,8 @@ def lib():
     L.ansx_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.ansx_workspace_bytes.restype = sz
     L.ansx_workspace_bytes.argtypes = [vp]
+    L.ansx_debug_set.restype = C.c_int
+    L.ansx_debug_set.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.ansx_host_log2.restype = C.c_double
     L.ansx_host_log2.argtypes = [C.c_double]
     L.ansx_selftest_log2.restype = C.c_int

@@ -44,6 +44,12 @@ class Context:
     def workspace_bytes(self):
         return L.lib().ansx_workspace_bytes(self._h)
 
+    def debug_set(self, name, value=None):
+        """Select one of the equivalent internal code paths (tests / experiments); value None or "" = default."""
+        st = L.lib().ansx_debug_set(self._h, name.encode(), None if value is None else str(value).encode())
+        if st != L.OK:
+            raise L.AnsxError(st, "ansx_debug_set(%s)" % name)
+
     # -- per-kernel timing (hipEvents inside the library)
     def profile(self, on=True):
         L.lib().ansx_profile_enable(self._h, int(on))

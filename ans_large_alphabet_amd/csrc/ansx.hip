@@ -45,6 +45,19 @@ struct ansx_ctx {
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
         stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
+    // Path-selection overrides for tests and experiments (every path must give identical bytes).
+    // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
+    // the per-call hot path never looks at the environment.
+    struct {
+        bool table16_fixup = false;   // ANSX_TEST_TABLE16_FIXUP: integer-state encoder fed by k_table16_from32
+        bool encode_gtab16 = false;   // ANSX_ENCODE_GTAB16: force the 16-byte-entry integer-state encoder
+        bool parse_generic = false;   // ANSX_PARSE_GENERIC: generic prelude parser kernel
+        bool decode_table = false;    // ANSX_DECODE_TABLE: slot -> symbol decoder tables
+        bool no_stream_lds = false;   // ANSX_NO_STREAM_LDS: staged decoder reads the stream from HBM
+        int decode_mode = 0;          // ANSX_DECODE_MODE: 0 auto, 1 "ring", 2 "staged"
+        u32 parse_stage_words = 0;    // ANSX_PARSE_STAGE_WORDS: 0 = default
+        bool model_unfused = false;   // ANSX_MODEL_UNFUSED: five-kernel model path even where the fused kernel applies
+    } dbg;
 };
 
 namespace {
@@ -126,7 +139,7 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     if (kind != ANSX_FOLD && kind != ANSX_RFOLD && kind != ANSX_MSB) return ANSX_ERR_ARG;
     if (kind == ANSX_MSB) {
         if (f != 0) return ANSX_ERR_ARG;  // ANSmsb has no fidelity parameter (methods.hpp:499-515)
-    } else if (f < 1 || f > 7) return ANSX_ERR_ARG;
+    } else if (f < 1 || f > ANSX_MAX_FIDELITY) return ANSX_ERR_ARG;  // see include/ansx.h
     if (n == 0) return ANSX_ERR_ARG;
     u32 bi = opts ? opts->block_ints : 0;
     u32 ck = opts ? opts->ckpt_interval : 0;
@@ -311,8 +324,8 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     // consumers of the 16-byte table entries that are certain before the frames are known: the
     // generic prelude writer (alphabets above 4096 slots) and the integer-state encoder (forced, or
     // scratch slots too far apart for the f64 encoder's 31-bit buffer offsets)
-    const bool test_fixup = getenv("ANSX_TEST_TABLE16_FIXUP") != nullptr;  // tests: integer-state encoder fed by k_table16_from32
-    const u32 always16 = (!test_fixup && (NSP > 4096 || (u64)scr_stride * 16 >= 0x7FFFFF00ull || getenv("ANSX_ENCODE_GTAB16"))) ? 1u : 0u;
+    const bool test_fixup = c->dbg.table16_fixup;  // tests: integer-state encoder fed by k_table16_from32
+    const u32 always16 = (!test_fixup && (NSP > 4096 || (u64)scr_stride * 16 >= 0x7FFFFF00ull || c->dbg.encode_gtab16)) ? 1u : 0u;
     for (u32 batch = 0; batch < nbatch; batch++) {
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
@@ -362,7 +375,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);
-    } else if (f64_ok && !getenv("ANSX_ENCODE_GTAB16")) {
+    } else if (f64_ok && !c->dbg.encode_gtab16) {
         // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
         LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
@@ -405,11 +418,9 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t pf_e = std::max<size_t>(20480, rup(((size_t)max_ns + 2) * 128, 16));
     const size_t pf_lds = pf_e + (size_t)ANSX_PF_SW * 64 * 4 + 21 * 64 * 4;
     u32 stage_words = ANSX_PF_SW;
-    if (const char* e = getenv("ANSX_PARSE_STAGE_WORDS")) {  // tests: force the in-kernel fallback
-        const long v = strtol(e, nullptr, 10);
-        if (v >= 2 && v <= (long)ANSX_PF_SW) stage_words = (u32)v & ~1u;
-    }
-    if ((u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024 && !getenv("ANSX_PARSE_GENERIC")) {
+    if (c->dbg.parse_stage_words >= 2 && c->dbg.parse_stage_words <= ANSX_PF_SW)  // tests: force the in-kernel fallback
+        stage_words = c->dbg.parse_stage_words & ~1u;
+    if ((u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024 && !c->dbg.parse_generic) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
@@ -427,7 +438,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t LDS_LIMIT = 150 * 1024;
     // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
     const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16);
-    if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !getenv("ANSX_DECODE_TABLE")) {
+    if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !c->dbg.decode_table) {
         // per-quad stream rings when every segment of a full block has the same length; the (at
         // most one) partial block of the container then reads its stream straight from HBM
         // (measured on MI355X, 256 Mi ints: rings 0.73 vs 0.76 ms at 16 Ki / 1024, 0.73 vs 1.85 ms at
@@ -438,8 +449,8 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         const bool ring_ok = g.ckpt != 0 && g.block_ints % g.ckpt == 0 && g.ckpt % 4 == 0
             && rs_tables + ring_lds <= 60 * 1024;
         const bool ring_pays = !staged_fits || 10 * (rs_tables + want_stream) > 16 * (rs_tables + ring_lds);
-        const char* force = getenv("ANSX_DECODE_MODE");  // tests: "ring" | "staged"
-        const bool use_ring = ring_ok && (force ? !strcmp(force, "ring") : ring_pays);
+        const int force = c->dbg.decode_mode;  // tests: 1 "ring" | 2 "staged"
+        const bool use_ring = ring_ok && (force ? force == 1 : ring_pays);
         if (use_ring) {
             const size_t lds = rs_tables + ring_lds;
             if (lds > 48 * 1024)
@@ -452,7 +463,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         }
         size_t lds = rs_tables;
         u32 stream_cap = 0;
-        if (staged_fits && !getenv("ANSX_NO_STREAM_LDS")) {
+        if (staged_fits && !c->dbg.no_stream_lds) {
             lds += want_stream;
             stream_cap = (u32)want_stream;
         }
@@ -534,7 +545,7 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
     if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
     if (H.kind > 2 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
-    if (H.kind == ANSX_MSB ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > 7)) return ANSX_ERR_FORMAT;
+    if (H.kind == ANSX_MSB ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > ANSX_MAX_FIDELITY)) return ANSX_ERR_FORMAT;
     *out = H;
     return ANSX_OK;
 }
@@ -619,7 +630,9 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if (P.g.nblocks != H.nblocks || P.g.nckf != H.ckpts_per_block || P.g.ckpt != H.ckpt_interval
             || P.lay.payload_off != H.payload_offset)
             return ANSX_ERR_FORMAT;
-        if (H.payload_offset + H.payload_bytes > in_bytes) return ANSX_ERR_FORMAT;
+        // (written so that a crafted payload_bytes near 2^64 cannot wrap the sum; payload_offset covers
+        // the index and the restart-point area, so this also places those inside the input)
+        if (H.payload_offset > in_bytes || H.payload_bytes > in_bytes - H.payload_offset) return ANSX_ERR_FORMAT;
         if (H.max_log2_frame > 31 || H.max_nsyms == 0 || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
         maxM = 1u << H.max_log2_frame;
         max_ns = H.max_nsyms;
@@ -679,7 +692,28 @@ int ansx_init(int device, ansx_ctx** out)
         delete c;
         return ANSX_ERR_HIP;
     }
+    static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC",
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_UNFUSED" };
+    for (const char* nm : names)
+        if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
+    return ANSX_OK;
+}
+
+int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
+{
+    if (!c || !name) return ANSX_ERR_ARG;
+    const bool on = value != nullptr && value[0] != 0 && strcmp(value, "0") != 0;
+    if (!strcmp(name, "ANSX_TEST_TABLE16_FIXUP")) c->dbg.table16_fixup = on;
+    else if (!strcmp(name, "ANSX_ENCODE_GTAB16")) c->dbg.encode_gtab16 = on;
+    else if (!strcmp(name, "ANSX_PARSE_GENERIC")) c->dbg.parse_generic = on;
+    else if (!strcmp(name, "ANSX_DECODE_TABLE")) c->dbg.decode_table = on;
+    else if (!strcmp(name, "ANSX_NO_STREAM_LDS")) c->dbg.no_stream_lds = on;
+    else if (!strcmp(name, "ANSX_MODEL_UNFUSED")) c->dbg.model_unfused = on;
+    else if (!strcmp(name, "ANSX_DECODE_MODE"))
+        c->dbg.decode_mode = !value ? 0 : !strcmp(value, "ring") ? 1 : !strcmp(value, "staged") ? 2 : 0;
+    else if (!strcmp(name, "ANSX_PARSE_STAGE_WORDS")) c->dbg.parse_stage_words = value ? (u32)strtoul(value, nullptr, 10) : 0u;
+    else return ANSX_ERR_ARG;
     return ANSX_OK;
 }
 

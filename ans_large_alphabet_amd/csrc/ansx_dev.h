@@ -197,19 +197,11 @@ ANSX_HD double ansx_div_int31(double a, double b)
 // the same VGPR (hipcc pads nothing inside asm).
 template <int CTRL> ANSX_D u32 quad_perm(u32 v)
 {
-#if defined(ANSX_DPP_BUILTIN)
-    // builtin DPP mov (the compiler pads/schedules the 2 wait states itself) + an empty asm on
-    // the result so that the mov can never be folded into its consumer (see above)
-    u32 r = (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-    asm volatile("" : "+v"(r));
-    return r;
-#else
     u32 r;
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf bound_ctrl:1"
                  : "=v"(r)
                  : "v"(v), "n"(CTRL & 3), "n"((CTRL >> 2) & 3), "n"((CTRL >> 4) & 3), "n"((CTRL >> 6) & 3));
     return r;
-#endif
 }
 
 // inclusive prefix sum over the 4 lanes of a quad; *total receives the quad sum

@@ -977,16 +977,12 @@ __device__ __forceinline__ void enc_update(enc_lane& L, u32 x, const enc_ent e, 
     u32 total;
     const u32 incl = quad_incl_scan(c, ql, &total);
     u8* a = out + (L.p + (incl - c));
-#ifndef ANSX_ABL_NOSTORE
     if (active) {
         if (k == 1) a[0] = (u8)eb;
         if (k >= 2) st_u16_unaligned(a, (u16)eb);
         if (k == 3) a[2] = (u8)(eb >> 16);
         if (rn) st_u32_unaligned(a + k, w);
     }
-#else
-    asm volatile("" ::"v"(a), "v"(eb), "v"(w));
-#endif
     L.p += total;
 }
 
@@ -1024,16 +1020,12 @@ __device__ __forceinline__ void enc_update_d(enc_lane& L, u32 x, const enc_ent_d
     u32 total;
     const u32 incl = quad_incl_scan(c, ql, &total);
     u8* a = out + (L.p + (incl - c));
-#ifndef ANSX_ABL_NOSTORE
     if (active) {
         if (k == 1) a[0] = (u8)eb;
         if (k >= 2) st_u16_unaligned(a, (u16)eb);
         if (k == 3) a[2] = (u8)(eb >> 16);
         if (rn) st_u32_unaligned(a + k, w);
     }
-#else
-    asm volatile("" ::"v"(a), "v"(eb), "v"(w));
-#endif
     L.p += total;
 }
 
@@ -1577,7 +1569,10 @@ __device__ __forceinline__ u32 parse_items_generic(const parse_hdr& H, u32 NSP, 
             if (consumed >= 64) {
                 consumed -= 64;
                 w0 = w1;
-                w1 = ld_u64_unaligned(bp + next_byte);  // the stream continues behind the prelude
+                // the stream continues behind the prelude (payload + 32 bytes of states); the refill never
+                // reads past the block's own bytes, whatever a malformed prelude claims
+                const u32 nb_ = next_byte + 8 <= sbytes - pos ? next_byte : sbytes - pos - 8;
+                w1 = ld_u64_unaligned(bp + nb_);
                 next_byte += 8;
             }
             return (u32)(v & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));

@@ -20,8 +20,12 @@ MAGIC = b"ANSXv1\x00\x00"
 
 
 def shard_blocks(n, block_ints, rank, world):
-    """Contiguous whole-block range of `rank`: returns (first_int, n_ints)."""
+    """Contiguous whole-block range of `rank`: returns (first_int, n_ints).  Every rank must own at
+    least one block (the codec rejects empty inputs, and an empty rank would leave the others waiting
+    in the gather): fewer blocks than ranks is a caller error, raised identically on every rank."""
     nblocks = (n + block_ints - 1) // block_ints
+    if nblocks < world:
+        raise ValueError("%d blocks cannot be sharded over %d ranks: use fewer ranks or smaller blocks" % (nblocks, world))
     b0 = rank * nblocks // world
     b1 = (rank + 1) * nblocks // world
     lo = min(n, b0 * block_ints)

@@ -69,6 +69,11 @@ typedef enum {
 
 #define ANSX_SINGLE_STREAM 0xFFFFFFFFu /* opts.block_ints: one plain reference stream          */
 #define ANSX_NO_CHECKPOINTS 0xFFFFFFFFu /* opts.ckpt_interval: no decoder restart points        */
+/* Largest fidelity accepted.  The reference instantiates ANSfold<1..8> (methods.hpp:529-567) but is only
+ * sound up to 7 (rfold<8> truncates symbols to u16, fold<8> can hit the u16 bail-out); here the
+ * per-block model state of a block (2^(f+9) symbol slots) must fit one CU's 160 KB of LDS, which holds up
+ * to f = 5 (16384 slots).  f = 6, 7 are rejected with ANSX_ERR_ARG (containers: ANSX_ERR_FORMAT). */
+#define ANSX_MAX_FIDELITY 5
 #define ANSX_DEFAULT_BLOCK_INTS 16384u
 #define ANSX_DEFAULT_CKPT_INTERVAL 1024u
 
@@ -136,6 +141,13 @@ int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_h
 int ansx_profile_enable(ansx_ctx* ctx, int on);
 int ansx_profile_reset(ansx_ctx* ctx);
 int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int* count);
+
+/* Test / experiment hook: select one of the equivalent internal code paths (all must produce identical
+ * bytes).  Names are those of the environment variables read once by ansx_init: ANSX_DECODE_MODE
+ * ("ring" | "staged" | ""), ANSX_DECODE_TABLE, ANSX_NO_STREAM_LDS, ANSX_PARSE_GENERIC,
+ * ANSX_PARSE_STAGE_WORDS (number), ANSX_ENCODE_GTAB16, ANSX_TEST_TABLE16_FIXUP, ANSX_MODEL_UNFUSED
+ * (flags: "1" on, "0"/""/NULL off).  Unknown name: ANSX_ERR_ARG. */
+int ansx_debug_set(ansx_ctx* ctx, const char* name, const char* value);
 
 /* Bytes of device workspace currently held by the context. */
 size_t ansx_workspace_bytes(const ansx_ctx* ctx);

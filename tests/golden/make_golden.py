@@ -91,11 +91,26 @@ def main():
                     if k == "rfold":
                         d = d % np.uint32(1 << 21)
                     large.append(entry(k, f, d, False, fam, seed))
+    # fidelities between the reference harness's own choices (every accepted value is pinned)
+    f24 = []
+    for k in ("fold", "rfold"):
+        for f in (2, 4):
+            for fam in FAMILIES:
+                for n in (5, 313, 4096, 70001):
+                    if fam == "distinct" and n > 65536:
+                        continue
+                    seed = 1000 * f + n
+                    d = ol.gen_inputs(fam, n, seed)
+                    if k == "rfold":
+                        d = d % np.uint32(1 << 21)
+                    f24.append(entry(k, f, d, False, fam, seed))
+    with open(os.path.join(HERE, "f24.json"), "w") as fh:
+        json.dump(f24, fh, indent=0)
     with open(os.path.join(HERE, "small.json"), "w") as fh:
         json.dump(small, fh, separators=(",", ":"))
     with open(os.path.join(HERE, "large.json"), "w") as fh:
         json.dump(large, fh, indent=0)
-    print("small:", len(small), "large:", len(large))
+    print("small:", len(small), "large:", len(large), "f24:", len(f24))
 
 
 if __name__ == "__main__":

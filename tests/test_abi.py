@@ -48,6 +48,8 @@ def test_bound_and_argument_validation(A):
             assert b >= 7 * (1 << 20)
     assert L.ansx_bound(A.FOLD, 0, 100, None) == 0      # fidelity out of range
     assert L.ansx_bound(A.FOLD, 8, 100, None) == 0
+    assert L.ansx_bound(A.FOLD, 6, 100, None) == 0      # above ANSX_MAX_FIDELITY (LDS limit, include/ansx.h)
+    assert L.ansx_bound(A.RFOLD, 4, 100, None) > 0
     assert L.ansx_bound(3, 1, 100, None) == 0           # unknown codec
     assert L.ansx_bound(A.MSB, 1, 100, None) == 0       # ANSmsb takes no fidelity
     assert L.ansx_bound(A.MSB, 0, 100, None) > 700

@@ -30,6 +30,10 @@ def test_shard_blocks_cover_and_align():
         for block in (64, 4096, 16384):
             for world in (1, 2, 3, 8):
                 pos = 0
+                if (n + block - 1) // block < world:  # an empty rank would hang the gather: refused up front
+                    with pytest.raises(ValueError):
+                        adist.shard_blocks(n, block, 0, world)
+                    continue
                 for r in range(world):
                     lo, cnt = adist.shard_blocks(n, block, r, world)
                     assert lo == pos and lo % block == 0 or cnt == 0

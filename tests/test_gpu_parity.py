@@ -89,6 +89,31 @@ def test_fold_blocks_match_oracle(A, ctx, f, fam):
     assert np.array_equal(codec.decode(cont, n), data)
 
 
+@pytest.mark.parametrize("kind", [ol.FOLD, ol.RFOLD])
+@pytest.mark.parametrize("f", [2, 4])
+def test_even_fidelities_match_oracle(A, ctx, kind, f):
+    """Every accepted fidelity is exercised (the reference harnesses use 1 and 5, BASELINE 1 and 3)."""
+    for fam in ("uniform20", "zipf20s1.2", "zipf24", "sparse_large", "boundaries", "constant"):
+        n = 40007
+        data = ol.gen_inputs(fam, n, seed=31 * f)
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        codec = codec_for(A, ctx, kind, f, block_ints=16384, ckpt_interval=1024)
+        cont = codec.encode(data)
+        check_container(A, cont, data, kind, f, 16384, 1024)
+        assert np.array_equal(codec.decode(cont, n), data), fam
+
+
+def test_fidelities_above_the_lds_limit_are_rejected(A, ctx):
+    """f = 6, 7 need more model state per block than a CU's LDS holds: ANSX_ERR_ARG, not a HIP error."""
+    data = ol.gen_inputs("uniform20", 5000, seed=3)
+    for f in (6, 7, 8):
+        for cls in (A.ANSfold, A.ANSrfold):
+            with pytest.raises(A.AnsxError) as ei:
+                cls(f, ctx=ctx).encode(data)
+            assert ei.value.status == 1
+
+
 @pytest.mark.parametrize("f", [1, 3, 5])
 @pytest.mark.parametrize("fam", ["uniform256", "uniform20", "geom0.01", "zipf20s1.2", "zipf24",
                                  "constant", "distinct", "sparse_large", "boundaries"])
@@ -154,8 +179,9 @@ def test_golden_fixtures_single_stream(A, ctx):
         assert np.array_equal(codec.decode(ref_stream, e["n"]), data)
 
 
-def test_golden_fixtures_large(A, ctx):
-    with open(os.path.join(GOLD, "large.json")) as fh:
+@pytest.mark.parametrize("fixture", ["large.json", "f24.json"])
+def test_golden_fixtures_large(A, ctx, fixture):
+    with open(os.path.join(GOLD, fixture)) as fh:
         gold = json.load(fh)
     for e in gold:
         data = ol.gen_inputs(e["family"], e["n"], e["seed"])
@@ -386,7 +412,7 @@ def test_corrupted_payload_never_faults(A, ctx):
 
 
 @pytest.mark.parametrize("kind,f", [(ol.FOLD, 1), (ol.RFOLD, 1), (ol.FOLD, 3)])
-def test_decoder_stream_modes(A, ctx, monkeypatch, kind, f):
+def test_decoder_stream_modes(A, ctx, kind, f):
     """The block decoder reads the stream through per-quad LDS rings, a staged copy of the whole
     block stream, or straight from HBM, with rank/select or slot->symbol tables: every combination
     must return the same ints (the default picks by LDS footprint)."""
@@ -398,10 +424,13 @@ def test_decoder_stream_modes(A, ctx, monkeypatch, kind, f):
         cont = codec.encode(data)
         for env in ({}, {"ANSX_DECODE_MODE": "ring"}, {"ANSX_DECODE_MODE": "staged"},
                     {"ANSX_DECODE_MODE": "staged", "ANSX_NO_STREAM_LDS": "1"}, {"ANSX_DECODE_TABLE": "1"}):
-            with monkeypatch.context() as m:
+            try:
                 for k, v in env.items():
-                    m.setenv(k, v)
+                    ctx.debug_set(k, v)
                 assert np.array_equal(codec.decode(cont, n), data), (block, ckpt, env)
+            finally:
+                for k in env:
+                    ctx.debug_set(k, None)
 
 
 def test_random_geometries_round_trip_and_match_oracle(A, ctx):
@@ -484,7 +513,7 @@ def test_default_stream_ordering_without_synchronize(A, ctx):
         assert bool(torch.equal(d_back, d_in)), rep
 
 
-def test_encoder_table_modes(A, ctx, monkeypatch):
+def test_encoder_table_modes(A, ctx):
     """Alphabets too large for the LDS-table encoder take the compact-table-from-HBM mode (f64 state,
     branch-free step, hand-counted vmcnt waits); ANSX_ENCODE_GTAB16 forces the older 16-byte-entry
     integer-state kernel.  Both must write byte-identical containers (and equal the oracle)."""
@@ -495,14 +524,16 @@ def test_encoder_table_modes(A, ctx, monkeypatch):
         cont = codec.encode(data)
         check_container(A, cont, data, ol.FOLD, f, 16384, 1024)
         for env in ("ANSX_ENCODE_GTAB16", "ANSX_TEST_TABLE16_FIXUP"):  # 16-byte entries written by the
-            with monkeypatch.context() as m:                             # model kernel / rebuilt afterwards
-                m.setenv(env, "1")
+            try:                                                         # model kernel / rebuilt afterwards
+                ctx.debug_set(env, "1")
                 cont16 = codec.encode(data)
+            finally:
+                ctx.debug_set(env, None)
             assert np.array_equal(cont, cont16), (fam, f, env)
         assert np.array_equal(codec.decode(cont, n), data)
 
 
-def test_prelude_parser_paths(A, ctx, monkeypatch):
+def test_prelude_parser_paths(A, ctx):
     """The decoder's prelude parser has a fast loop (alphabets whose interpolative values fit 16 bits,
     the first 512 prelude bytes staged in LDS), an in-kernel fallback for lanes whose prelude
     outgrows the staged bytes, and a generic kernel.  Valid preludes of such alphabets stay below
@@ -522,12 +553,16 @@ def test_prelude_parser_paths(A, ctx, monkeypatch):
     assert min(preludes) > 300, preludes
     assert parts["header"].max_nsyms + (1 << parts["header"].max_log2_frame) + 3 <= 65535  # fast kernel eligible
     assert np.array_equal(codec.decode(cont, n), data)             # fast loop
-    for words in ("64", "32", "2"):                                # 256 / 128 / 8 staged bytes: fallback lanes
-        monkeypatch.setenv("ANSX_PARSE_STAGE_WORDS", words)
-        assert np.array_equal(codec.decode(cont, n), data), words
-    monkeypatch.delenv("ANSX_PARSE_STAGE_WORDS")
-    monkeypatch.setenv("ANSX_PARSE_GENERIC", "1")                  # generic kernel
-    assert np.array_equal(codec.decode(cont, n), data)
+    try:
+        for words in ("64", "32", "2"):                            # 256 / 128 / 8 staged bytes: fallback lanes
+            ctx.debug_set("ANSX_PARSE_STAGE_WORDS", words)
+            assert np.array_equal(codec.decode(cont, n), data), words
+        ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
+        ctx.debug_set("ANSX_PARSE_GENERIC", "1")                   # generic kernel
+        assert np.array_equal(codec.decode(cont, n), data)
+    finally:
+        ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
+        ctx.debug_set("ANSX_PARSE_GENERIC", None)
 
 
 @pytest.mark.parametrize("f", [1, 3])

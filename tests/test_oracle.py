@@ -101,8 +101,9 @@ def test_golden_small():
         assert np.array_equal(ol.oracle_decode(KIND[e["kind"]], e["f"], ref_stream, e["n"]), data), tag
 
 
-def test_golden_large():
-    gold = _load("large.json")
+@pytest.mark.parametrize("fixture", ["large.json", "f24.json"])
+def test_golden_large(fixture):
+    gold = _load(fixture)
     for e in gold:
         data = ol.gen_inputs(e["family"], e["n"], e["seed"])
         if e["kind"] == "rfold":

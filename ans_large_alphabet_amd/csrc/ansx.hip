@@ -15,6 +15,7 @@
 
 #include "ansx_kernels.h"
 #include "ansx_rfold.h"
+#include "ansx_model.h"
 
 namespace {
 
@@ -45,6 +46,9 @@ struct ansx_ctx {
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
         stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
+    // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
+    // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
+    std::map<u64, u32> ns_hint;
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
     // the per-call hot path never looks at the environment.
@@ -56,7 +60,9 @@ struct ansx_ctx {
         bool no_stream_lds = false;   // ANSX_NO_STREAM_LDS: staged decoder reads the stream from HBM
         int decode_mode = 0;          // ANSX_DECODE_MODE: 0 auto, 1 "ring", 2 "staged"
         u32 parse_stage_words = 0;    // ANSX_PARSE_STAGE_WORDS: 0 = default
-        bool model_unfused = false;   // ANSX_MODEL_UNFUSED: five-kernel model path even where the fused kernel applies
+        bool model_fused = false;     // ANSX_MODEL_FUSED: the single LDS-resident model kernel instead of the five tailored ones
+        bool model_sync = false;      // ANSX_MODEL_SYNC: always discover the alphabet with the mid-call read-back
+        u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
     } dbg;
 };
 
@@ -240,9 +246,18 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
 }
 
 // --------------------------------------------------------------------------------- encode
-int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap,
-    size_t* out_bytes, hipStream_t s)
+constexpr int ANSX_RETRY_GENERAL = -1;  // internal: an optimistic assumption did not hold, repeat without it
+
+// ns_cap == 0: discovery mode -- the largest alphabet / frame of the call are read back between the
+// model kernels and the encoder launch (one host round trip per candidate batch).
+// ns_cap != 0: optimistic mode -- the caller has seen this geometry before (alphabet hint): the first
+// candidate batch is assumed to settle every block, frames are assumed to stay within 2^16 and alphabets
+// within ns_cap, so everything is launched back to back; the assumptions are checked on the words that
+// come back with the output size anyway, and a miss returns ANSX_RETRY_GENERAL.
+int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap,
+    size_t* out_bytes, hipStream_t s, u32* seen_ns, u32 ns_cap)
 {
+    const bool optimistic = ns_cap != 0;
     const ansx_geo& g = P.g;
     const u32 NB = g.nblocks, NSP = P.NSP, f = g.f;
     const size_t scr_stride = rup(block_bound(g.kind, f, g.block_ints) + 16, 256);
@@ -335,6 +350,11 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
             (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u, always16);
+        if (optimistic) {  // checked after the fact (blocks left undecided carry no model and are skipped)
+            max_logM = 16;
+            max_ns = ns_cap;
+            break;
+        }
         HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         int st0 = flags_to_status(c->h_pin[ANSX_G_ERR]);
@@ -395,12 +415,188 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (optimistic) {
+        if (c->h_pin[ANSX_G_ERR] & (1u << 6)) return ANSX_ERR_DOMAIN;
+        if (c->h_pin[ANSX_G_PAD] != 0 || c->h_pin[ANSX_G_MAXLOGM] > 16 || c->h_pin[ANSX_G_MAXNSYMS] > ns_cap)
+            return ANSX_RETRY_GENERAL;
+    }
     int st = flags_to_status(c->h_pin[ANSX_G_ERR]);
     if (st) return st;
+    *seen_ns = c->h_pin[ANSX_G_MAXNSYMS];
     u64 payload;
     memcpy(&payload, (u8*)c->h_pin + 16, 8);
     *out_bytes = (size_t)(P.lay.payload_off + payload);
     return ANSX_OK;
+}
+
+// LDS carve of k_model_fused for `cap` symbols (a multiple of 8), see ansx_model.h
+ansx_model_lds model_layout(u32 cap)
+{
+    ansx_model_lds L;
+    L.cap = cap;
+    L.nc = cap <= 1024 ? 4u : (cap <= 2560 ? 2u : 1u);
+    L.natt = cap <= 1024 ? 8u : 4u;  // candidate rows are the largest region: fewer per batch for big alphabets
+    const u32 A = L.nc * (cap + 8) * 4;
+    u32 off;
+    if (L.nc == 4) {  // pairs | yF (12 cap bytes) live in histogram copies 1..3, dead once copy 0 holds the sums
+        L.off_pairs = (cap + 8) * 4;
+        off = A;
+    } else {
+        L.off_pairs = A;
+        off = A + 12 * cap;
+    }
+    L.off_yF = L.off_pairs + 4 * cap;
+    L.off_S = off;
+    const u32 sbytes = L.natt * cap * 2;  // >= 8 cap: the entropy terms come first
+    if (sbytes >= 8 * cap + ANSX_MODEL_SORT_BYTES) {
+        L.off_E = off + 8 * cap;  // sort scratch behind the entropy terms
+        off += sbytes;
+    } else {
+        L.off_E = off + sbytes;
+        off += sbytes + (u32)rup(ANSX_MODEL_SORT_BYTES, 16);
+    }
+    L.off_pos = off;
+    off += (u32)rup(2 * cap, 16);
+    L.off_ffs = off;
+    off += (u32)rup(4 * (cap + 4), 16);
+    L.off_X = off;
+    off += 256 * 8;
+    if (4 * cap >= 256 * 8) L.off_X1 = L.off_pairs;  // pairs are dead once yF / ffs exist
+    else {
+        L.off_X1 = off;
+        off += 256 * 8;
+    }
+    L.total = off;
+    return L;
+}
+
+// Optimistic encode, fused form: ONE model kernel per block with everything in LDS (sized from the context's
+// alphabet hint), no host round trip before the final size read-back.  Any block that does not fit the
+// assumptions (alphabet above the hint, frame above 2^16) raises the violation flag and the caller
+// repeats the call on the general path.
+int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes,
+    hipStream_t s, u32 ns_cap, u32* seen_ns)
+{
+    const ansx_geo& g = P.g;
+    const u32 NB = g.nblocks, NSP = P.NSP, f = g.f;
+    const size_t scr_stride = rup(block_bound(g.kind, f, g.block_ints) + 16, 256);
+    if (cap < P.lay.payload_off) return ANSX_ERR_CAPACITY;
+    if ((u64)scr_stride * 16 >= 0x7FFFFF00ull) return ANSX_RETRY_GENERAL;
+    const ansx_model_lds ML = model_layout(ns_cap);
+    if (ML.total > 150 * 1024) return ANSX_RETRY_GENERAL;
+    int rc;
+    if (!c->log2lut.p) {  // stage-1 table of the portable log2, once per context (1.5 MB)
+        if ((rc = ensure(c, c->log2lut, (size_t)65536 * sizeof(ansx_log2_ent)))) return rc;
+        LAUNCH(c, "k_build_log2_lut", k_build_log2_lut, 256, 256, 0, s, (ansx_log2_ent*)c->log2lut.p);
+    }
+    if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
+    if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
+    if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
+    if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
+    u32* gflags = (u32*)c->misc.p;
+    u64* result = (u64*)((u8*)c->misc.p + 16);
+    ansx_blk* blk = (ansx_blk*)c->blk.p;
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
+    HIPCHK(c, hipMemsetAsync(blk, 0, (size_t)NB * sizeof(ansx_blk), s));
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
+    const u32* src = d_in;
+    const u32* mostfreq = nullptr;
+    if (g.kind == ANSX_RFOLD) {
+        const u32 T = fold_T(f);
+        if ((rc = ensure(c, c->mapped, (size_t)g.n * 4))) return rc;
+        if ((rc = ensure(c, c->mostfreq, (size_t)NB * T * 4))) return rc;
+        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s);
+        if (rc) return rc;
+        src = (const u32*)c->mapped.p;
+        mostfreq = (const u32*)c->mostfreq.p;
+    }
+    if (ns_cap <= 1024) {
+        if (ML.total > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_model_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML.total));
+        LAUNCH(c, "k_model_fused", (k_model_fused<4>), NB, 256, ML.total, s, src, g, NSP, ML,
+            (const ansx_log2_ent*)c->log2lut.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq,
+            gflags, 1u << 30);
+    } else {
+        if (ML.total > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_model_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML.total));
+        LAUNCH(c, "k_model_fused", (k_model_fused<16>), NB, 256, ML.total, s, src, g, NSP, ML,
+            (const ansx_log2_ent*)c->log2lut.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq,
+            gflags, 1u << 30);
+    }
+    u64* ck_state = (u64*)(d_out + P.lay.ckstate_off);
+    u32* ck_off = (u32*)(d_out + P.lay.ckoff_off);
+    const u32 lds_stride = ns_cap | 1u;  // odd stride spreads the 16 tables over the banks
+    const size_t enc_lds = (size_t)16 * lds_stride * 4;
+    if (enc_lds <= 40 * 1024) {
+        LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off);
+    } else {
+        LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
+            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off);
+    }
+    u64* boff = (u64*)(d_out + P.lay.index_off);
+    LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off, (u64)cap, gflags);
+    LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p, (u64)scr_stride,
+        d_out + P.lay.payload_off, gflags);
+    LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (getenv("ANSX_DBG_TIMES")) {
+        u64 tt[16];
+        (void)hipMemcpy(tt, (u8*)c->misc.p + 64, sizeof(tt), hipMemcpyDeviceToHost);
+        fprintf(stderr, "phases(10ns ticks): hist %lld reduce %lld sortH %lld P4 %lld P5a %lld P5b %lld sat %lld XH %lld P7 %lld table %lld prelude %lld\n",
+            (long long)(tt[1]-tt[0]),(long long)(tt[2]-tt[1]),(long long)(tt[3]-tt[2]),(long long)(tt[4]-tt[3]),(long long)(tt[5]-tt[4]),(long long)(tt[6]-tt[5]),(long long)(tt[7]-tt[6]),(long long)(tt[8]-tt[7]),(long long)(tt[9]-tt[8]),(long long)(tt[10]-tt[9]),(long long)(tt[11]-tt[10]));
+    }
+    const u32 fl = c->h_pin[ANSX_G_ERR];
+    if (fl & (1u << 6)) return ANSX_ERR_DOMAIN;
+    if (fl & (1u << ANSX_G_VIOL_BIT)) return ANSX_RETRY_GENERAL;
+    int st = flags_to_status(fl);
+    if (st) return st;
+    *seen_ns = c->h_pin[ANSX_G_MAXNSYMS];
+    u64 payload;
+    memcpy(&payload, (u8*)c->h_pin + 16, 8);
+    *out_bytes = (size_t)(P.lay.payload_off + payload);
+    return ANSX_OK;
+}
+
+int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes,
+    hipStream_t s)
+{
+    // The first call of a geometry discovers its alphabet size with a mid-call read-back; later calls
+    // are launched back to back on that hint and repeat (rarely) if the input outgrew it.
+    const u64 key = ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
+    u32 seen = 0;
+    int rc = ANSX_RETRY_GENERAL;
+    const auto it = c->ns_hint.find(key);
+    const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
+    const bool eligible = !P.plain && hint != 0 && P.NSP <= 4096 && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
+        && !c->dbg.model_sync;
+    if (eligible) {
+        u32 ns_cap = (hint + 7u) & ~7u;
+        if (ns_cap < 64) ns_cap = 64;
+        if (ns_cap > P.NSP) ns_cap = P.NSP;
+        // (k_model_fused: the LDS-resident single-kernel model, measured slower than the five tailored
+        // kernels -- DESIGN.md section 6 -- and therefore opt-in)
+        if (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK)
+            rc = encode_fast(c, P, d_in, d_out, cap, out_bytes, s, ns_cap, &seen);
+        else
+            rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, ns_cap);
+    }
+    bool missed = false;
+    if (rc == ANSX_RETRY_GENERAL) {
+        missed = eligible;
+        rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
+    }
+    if (rc == ANSX_OK && !P.plain) {
+        // a miss raises the hint past what was seen, so inputs whose alphabets creep upwards do not
+        // miss on every call
+        const u32 want = missed ? seen + seen / 8 + 8 : seen;
+        u32& h = c->ns_hint[key];
+        if (want > h) h = want;
+    }
+    return rc;
 }
 
 // --------------------------------------------------------------------------------- decode
@@ -693,7 +889,7 @@ int ansx_init(int device, ansx_ctx** out)
         return ANSX_ERR_HIP;
     }
     static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC",
-        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_UNFUSED" };
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
@@ -709,10 +905,12 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_PARSE_GENERIC")) c->dbg.parse_generic = on;
     else if (!strcmp(name, "ANSX_DECODE_TABLE")) c->dbg.decode_table = on;
     else if (!strcmp(name, "ANSX_NO_STREAM_LDS")) c->dbg.no_stream_lds = on;
-    else if (!strcmp(name, "ANSX_MODEL_UNFUSED")) c->dbg.model_unfused = on;
+    else if (!strcmp(name, "ANSX_MODEL_FUSED")) c->dbg.model_fused = on;
+    else if (!strcmp(name, "ANSX_MODEL_SYNC")) c->dbg.model_sync = on;
     else if (!strcmp(name, "ANSX_DECODE_MODE"))
         c->dbg.decode_mode = !value ? 0 : !strcmp(value, "ring") ? 1 : !strcmp(value, "staged") ? 2 : 0;
     else if (!strcmp(name, "ANSX_PARSE_STAGE_WORDS")) c->dbg.parse_stage_words = value ? (u32)strtoul(value, nullptr, 10) : 0u;
+    else if (!strcmp(name, "ANSX_NS_HINT")) c->dbg.ns_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else return ANSX_ERR_ARG;
     return ANSX_OK;
 }

@@ -802,47 +802,16 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
     return c;
 }
 
-// IPT > 0: alphabets of at most 256 * IPT slots in frames up to 2^16 -- inc[] lives in LDS and is
-// built from the compact 4-byte table entries, and every thread keeps the codes of its <= IPT items
-// from the length pass for the packing pass (the workgroup is a latency chain otherwise: 16-byte
-// table entries, inc[] through global memory behind a fence, two tree descents per item).
+// Interpolative prelude of one block from inc[] in LDS (workgroup of 256 threads, every thread calls
+// this): codes -> lengths -> exclusive scan -> bit buffer -> bytes at `out` (rfold header first).
+// IPT > 0: at most 256 * IPT symbols, every thread keeps the codes of its <= IPT items from the length
+// pass for the packing pass (one tree descent per item); IPT == 0: any alphabet, two descents.
+// off: [ns] u32, bits: [ns + 1] u32 (LDS; 31 bits per item is the format's ceiling), sh_part: 8 u32.
 template <int IPT>
-__global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
-    const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
-    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
+__device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
+    u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid)
 {
     constexpr bool SMALL = IPT > 0;
-    extern __shared__ u32 lds32[];
-    __shared__ u32 sh_part[8];
-    const u32 tid = threadIdx.x;
-    const u32 b = blockIdx.x;
-    ansx_blk* B = &blk[b];
-    if (B->status) {
-        if (tid == 0) {
-            B->prelude_bytes = 0;
-        }
-        return;
-    }
-    const u32 ns = B->max_sym + 1;
-    const u32 logM = B->logM;
-    u32* off = lds32;         // [ns]
-    u32* bits = lds32 + NSP;  // bit buffer
-    u32* inc = SMALL ? lds32 + 2 * NSP : incbuf + (u64)b * NSP;
-    if (SMALL) {
-        const u32* t32 = tab32 + (u64)b * NSP;
-        for (u32 s = tid; s < ns; s += 256) {
-            const u32 e = t32[s];
-            inc[s] = (e >> 16) + (e & 0xFFFFu) + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
-        }
-    } else {
-        const ansx_enc_entry* tab = table + (u64)b * NSP;
-        for (u32 s = tid; s < ns; s += 256) {
-            ansx_enc_entry e = tab[s];
-            inc[s] = e.base + e.freq + s;
-        }
-        __threadfence_block();
-    }
-    __syncthreads();
     const u64 u = ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
     if (SMALL) {
@@ -892,7 +861,6 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i));
     }
     __syncthreads();
-    u8* out = scratch + (u64)b * scr_stride;
     u32 p = 0;
     if (g.kind == 1) {  // ans_reorder_fold.hpp:132-154
         const u32 T = fold_T(g.f);
@@ -927,6 +895,49 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         B->hdr_bytes = hdr;
         B->prelude_bytes = p + nbytes;
     }
+}
+
+// IPT > 0: alphabets of at most 256 * IPT slots in frames up to 2^16 -- inc[] lives in LDS and is
+// built from the compact 4-byte table entries (the workgroup is a latency chain otherwise: 16-byte
+// table entries, inc[] through global memory behind a fence, two tree descents per item).
+template <int IPT>
+__global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
+    const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
+{
+    constexpr bool SMALL = IPT > 0;
+    extern __shared__ u32 lds32[];
+    __shared__ u32 sh_part[8];
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    ansx_blk* B = &blk[b];
+    if (B->status || !B->resolved) {  // (unresolved: optimistic single-batch call, the host repeats it)
+        if (tid == 0) {
+            B->prelude_bytes = 0;
+        }
+        return;
+    }
+    const u32 ns = B->max_sym + 1;
+    const u32 logM = B->logM;
+    u32* off = lds32;         // [ns]
+    u32* bits = lds32 + NSP;  // bit buffer
+    u32* inc = SMALL ? lds32 + 2 * NSP : incbuf + (u64)b * NSP;
+    if (SMALL) {
+        const u32* t32 = tab32 + (u64)b * NSP;
+        for (u32 s = tid; s < ns; s += 256) {
+            const u32 e = t32[s];
+            inc[s] = (e >> 16) + (e & 0xFFFFu) + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+        }
+    } else {
+        const ansx_enc_entry* tab = table + (u64)b * NSP;
+        for (u32 s = tid; s < ns; s += 256) {
+            ansx_enc_entry e = tab[s];
+            inc[s] = e.base + e.freq + s;
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1232,7 +1243,8 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         for (u32 j = 0; j < 16; j++) {
             const u32 bj = b0 + j;
             if (bj >= g.nblocks) break;
-            const u32 nsj = blk[bj].max_sym + 1;
+            u32 nsj = blk[bj].max_sym + 1;
+            nsj = nsj < lds_stride ? nsj : lds_stride;  // (a block beyond the hint-sized LDS carries a status and is skipped)
             const u32* src32 = tab32 + (u64)bj * NSP;
             for (u32 s = threadIdx.x; s < nsj; s += 64) lds_tab[j * lds_stride + s] = src32[s];
         }
@@ -1240,7 +1252,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     }
     if (b >= g.nblocks) return;
     ansx_blk* B = &blk[b];
-    if (B->status) {
+    if (B->status || !B->resolved) {
         if (ql == 0) B->stream_bytes = 0;
         return;
     }

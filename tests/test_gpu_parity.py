@@ -28,8 +28,13 @@ def A():
     return A_
 
 
-@pytest.fixture(scope="module")
-def ctx(A, oracle_built):
+@pytest.fixture(scope="module", params=["learned", "hinted", "fused"])
+def ctx(A, oracle_built, request):
+    """"learned": a fresh context -- the first call per geometry discovers the alphabet size with a
+    mid-call read-back, later ones are launched back to back on the learned hint.  "hinted": the hint
+    is forced from the first call on (ANSX_NS_HINT), so every eligible encode of the suite takes the
+    read-back-free path; inputs that outgrow it repeat on the discovery path.  "fused": additionally the
+    single LDS-resident model kernel (k_model_fused, opt-in) replaces the five tailored ones."""
     # Same order as bench.py: torch (which bundles its own HIP runtime) initialises the device
     # first, libansx then shares that runtime.  On a fresh box the first `import torch` can take
     # minutes while the image pages in; doing it here keeps that out of the individual tests.
@@ -40,7 +45,12 @@ def ctx(A, oracle_built):
             torch.zeros(1, device="cuda")
     except ImportError:
         pass
-    return A.Context(0)
+    c = A.Context(0)
+    if request.param != "learned":
+        c.debug_set("ANSX_NS_HINT", "4096")
+    if request.param == "fused":
+        c.debug_set("ANSX_MODEL_FUSED", "1")
+    return c
 
 
 def codec_for(A, ctx, kind, f, **kw):
@@ -600,3 +610,71 @@ def test_msb_blocks_match_oracle(A, ctx, fam):
         exp, _, _, _ = ol.oracle_encode(ol.MSB, 0, data[:9001])
         assert np.array_equal(s, exp)
         assert np.array_equal(codec.decode(exp, 9001), data[:9001])
+
+
+def _kernels_of(ctx, fn):
+    ctx.profile(True)
+    ctx.profile_reset()
+    try:
+        out = fn()
+        names = [k for k, _ms, _n in ctx.profile_get()]
+    finally:
+        ctx.profile(False)
+    return out, names
+
+
+@pytest.mark.parametrize("kind,f,fam", [(ol.FOLD, 1, "zipf20s1.2"), (ol.FOLD, 3, "zipf24"), (ol.RFOLD, 1, "zipf20s1.2"),
+                                         (ol.MSB, 0, "sparse_large"), (ol.FOLD, 2, "uniform20")])
+def test_hinted_paths_run_and_match(A, kind, f, fam, oracle_built):
+    """Alphabet hint: learned on the first call (mid-call read-back), used from the second on (no
+    read-back; optionally the fused model kernel); a hint that is too small, or an input that outgrows
+    it, repeats on the discovery path.  All byte-identical."""
+    n = 5 * 16384 + 333
+    data = ol.gen_inputs(fam, n, seed=77)
+    if kind == ol.RFOLD:
+        data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    wide = ol.gen_inputs("uniform24" if kind != ol.RFOLD else "uniform20", n, seed=78)
+    for fused in (False, True):
+        c = A.Context(0)
+        if fused:
+            c.debug_set("ANSX_MODEL_FUSED", "1")
+        codec = codec_for(A, c, kind, f, block_ints=16384, ckpt_interval=1024)
+        first, k1 = _kernels_of(c, lambda: codec.encode(data))
+        assert "k_fold_hist" in k1 and "k_model_fused" not in k1
+        second, k2 = _kernels_of(c, lambda: codec.encode(data))
+        if fused:
+            assert "k_model_fused" in k2 and "k_fold_hist" not in k2 and "k_scale_attempts" not in k2
+        else:
+            assert k2.count("k_fold_hist") == 1 and "k_model_fused" not in k2
+        assert np.array_equal(first, second)
+        check_container(A, second, data, kind, f, 16384, 1024)
+        # an input with a larger alphabet than the learned hint: miss -> discovery path, hint grows
+        third, k3 = _kernels_of(c, lambda: codec.encode(wide))
+        check_container(A, third, wide, kind, f, 16384, 1024)
+        assert np.array_equal(codec.decode(third, n), wide)
+        # and a forced tiny hint
+        c.debug_set("ANSX_NS_HINT", "8")
+        fourth, k4 = _kernels_of(c, lambda: codec.encode(data))
+        assert np.array_equal(first, fourth)
+        assert "k_fold_hist" in k4 and (("k_model_fused" in k4) == fused)  # tried, missed, repeated
+        c.close()
+
+
+def test_fused_model_many_geometries(A, oracle_built):
+    """Fused path over block sizes / lengths incl. partial and tiny blocks, constant blocks (16 frame
+    sizes: more than one candidate batch) and blocks that take the reference's degenerate exits."""
+    c = A.Context(0)
+    c.debug_set("ANSX_NS_HINT", "1024")
+    c.debug_set("ANSX_MODEL_FUSED", "1")
+    rng = np.random.default_rng(11)
+    for block, ckpt, n in ((16384, 1024, 40000), (4096, 512, 12289), (1024, 256, 5000), (64, 0, 1000), (16384, 1024, 3)):
+        for fam in ("zipf20s1.2", "uniform256", "geom0.4", "constant", "boundaries", "sparse_large"):
+            data = ol.gen_inputs(fam, n, seed=int(rng.integers(1 << 30)))
+            for kind, f in ((ol.FOLD, 1), (ol.MSB, 0), (ol.RFOLD, 1)):
+                d = np.minimum(data, np.uint32((1 << 30) - 1 - 256)) if kind == ol.RFOLD else data
+                kw = dict(block_ints=block, ckpt_interval=ckpt if ckpt else A.NO_CHECKPOINTS)
+                codec = codec_for(A, c, kind, f, **kw)
+                cont = codec.encode(d)
+                check_container(A, cont, d, kind, f, block, ckpt)
+                assert np.array_equal(codec.decode(cont, d.size), d), (block, fam, kind)
+    c.close()

@@ -6,8 +6,9 @@ test oracle (oracle/), and there is no CPU fallback.
 """
 from ._lib import (AnsxError, DEFAULT_BLOCK_INTS, DEFAULT_CKPT_INTERVAL, FOLD, MSB, NO_CHECKPOINTS,
                    RFOLD, SINGLE_STREAM, build_library, lib)
-from .codec import ANSfold, ANSmsb, ANSrfold, Context, make_opts, parse_container
+from .codec import (ANSfold, ANSmsb, ANSrfold, Context, generate_dev, generate_host, make_opts, parse_container,
+                    parse_dist)
 
 __all__ = ["ANSfold", "ANSrfold", "ANSmsb", "MSB", "Context", "AnsxError", "build_library", "lib", "make_opts",
-           "parse_container", "FOLD", "RFOLD", "SINGLE_STREAM", "NO_CHECKPOINTS",
+           "parse_container", "generate_dev", "generate_host", "parse_dist", "FOLD", "RFOLD", "SINGLE_STREAM", "NO_CHECKPOINTS",
            "DEFAULT_BLOCK_INTS", "DEFAULT_CKPT_INTERVAL"]

@@ -17,12 +17,14 @@ NO_CHECKPOINTS = 0xFFFFFFFF
 DEFAULT_BLOCK_INTS = 16384
 DEFAULT_CKPT_INTERVAL = 1024
 MAX_FIDELITY = 5
+GEN_UNIFORM, GEN_GEOMETRIC, GEN_ZIPF = 0, 1, 2
 
 EXPORTS = [
     "ansx_init", "ansx_destroy", "ansx_strerror", "ansx_last_hip_error", "ansx_codec_name",
     "ansx_bound", "ansx_encode", "ansx_decode", "ansx_encode_dev", "ansx_decode_dev",
     "ansx_container_info", "ansx_profile_enable", "ansx_profile_reset", "ansx_profile_get",
     "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div", "ansx_debug_set",
+    "ansx_generate_dev", "ansx_generate_host", "ansx_last_encode_stats", "ansx_merge_containers_dev",
 ]
 
 
@@ -37,6 +39,11 @@ class ContainerHeader(C.Structure):
                 ("nblocks", C.c_uint32), ("max_log2_frame", C.c_uint32), ("max_nsyms", C.c_uint32),
                 ("ckpts_per_block", C.c_uint32), ("payload_bytes", C.c_uint64),
                 ("payload_offset", C.c_uint64)]
+
+
+class EncodeStats(C.Structure):
+    _fields_ = [("max_nsyms", C.c_uint32), ("max_log2_frame", C.c_uint32), ("near_threshold_decisions", C.c_uint32),
+                ("path", C.c_uint32)]
 
 
 class KernelTime(C.Structure):
@@ -115,6 +122,14 @@ def lib():
     L.ansx_profile_get.argtypes = [vp, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.ansx_workspace_bytes.restype = sz
     L.ansx_workspace_bytes.argtypes = [vp]
+    L.ansx_generate_dev.restype = C.c_int
+    L.ansx_generate_dev.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64, vp, sz, vp]
+    L.ansx_generate_host.restype = C.c_int
+    L.ansx_generate_host.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64, vp, sz]
+    L.ansx_merge_containers_dev.restype = C.c_int
+    L.ansx_merge_containers_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int, vp, sz, C.POINTER(sz), vp]
+    L.ansx_last_encode_stats.restype = C.c_int
+    L.ansx_last_encode_stats.argtypes = [vp, C.POINTER(EncodeStats)]
     L.ansx_debug_set.restype = C.c_int
     L.ansx_debug_set.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.ansx_host_log2.restype = C.c_double

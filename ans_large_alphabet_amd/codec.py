@@ -44,6 +44,23 @@ class Context:
     def workspace_bytes(self):
         return L.lib().ansx_workspace_bytes(self._h)
 
+    def merge_containers_dev(self, part_ptrs, part_bytes, out_ptr, out_capacity, stream=None):
+        """Native root-side concatenation of rank containers (device pointers, list order) -> bytes written."""
+        k = len(part_ptrs)
+        ptrs = (C.c_void_p * k)(*part_ptrs)
+        sizes = (C.c_size_t * k)(*part_bytes)
+        nb = C.c_size_t(0)
+        st = L.lib().ansx_merge_containers_dev(self._h, ptrs, sizes, k, out_ptr, out_capacity, C.byref(nb), stream)
+        if st != L.OK:
+            raise L.AnsxError(st, "ansx_merge_containers_dev")
+        return nb.value
+
+    def last_encode_stats(self):
+        """dict(max_nsyms, max_log2_frame, near_threshold_decisions, path) of the most recent encode."""
+        st = L.EncodeStats()
+        L.lib().ansx_last_encode_stats(self._h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in L.EncodeStats._fields_}
+
     def debug_set(self, name, value=None):
         """Select one of the equivalent internal code paths (tests / experiments); value None or "" = default."""
         st = L.lib().ansx_debug_set(self._h, name.encode(), None if value is None else str(value).encode())
@@ -170,3 +187,42 @@ def parse_container(buf):
         "ckpt_off": ck_off.reshape(nb, H.ckpts_per_block) if nck else ck_off.reshape(nb, 0),
         "ckpt_state": ck_state.reshape(nb, H.ckpts_per_block, 4) if nck else ck_state.reshape(nb, 0, 4),
     }
+
+
+# ---------------------------------------------------------------- synthetic inputs (generate_inputs.cpp)
+
+def parse_dist(spec):
+    """'uniform<lo>-<hi>' | 'uniform<bits>' (0 .. 2^bits - 1, generate_inputs.cpp:94-101) | 'geom<p>' |
+    'zipf<log2 n>[s<q>]' (values 1 .. 2^log2n, exponent q, default 1.0 as zipf_dist.hpp:39-40)
+    -> (dist, a, b)"""
+    if spec.startswith("uniform"):
+        body = spec[7:]
+        if "-" in body:
+            lo, hi = body.split("-")
+            return L.GEN_UNIFORM, float(int(lo)), float(int(hi))
+        return L.GEN_UNIFORM, 0.0, float((1 << int(body)) - 1)
+    if spec.startswith("geom"):
+        return L.GEN_GEOMETRIC, float(spec[4:]), 0.0
+    if spec.startswith("zipf"):
+        body = spec[4:]
+        lg, q = (body.split("s") + ["1.0"])[:2] if "s" in body else (body, "1.0")
+        return L.GEN_ZIPF, float(1 << int(lg)), float(q)
+    raise ValueError("unknown distribution %r" % (spec,))
+
+
+def generate_host(spec, n, seed=0, first_index=0):
+    """n values of the named distribution on the CPU (same values as generate_dev)."""
+    dist, a, b = parse_dist(spec)
+    out = np.empty(n, dtype=np.uint32)
+    st = L.lib().ansx_generate_host(dist, a, b, seed, first_index, out.ctypes.data, n)
+    if st != L.OK:
+        raise L.AnsxError(st, "ansx_generate_host")
+    return out
+
+
+def generate_dev(ctx, spec, out_ptr, n, seed=0, first_index=0, stream=None):
+    """Fill device memory at out_ptr (n x uint32) with the named distribution; asynchronous on `stream`."""
+    dist, a, b = parse_dist(spec)
+    st = L.lib().ansx_generate_dev(ctx.handle, dist, a, b, seed, first_index, out_ptr, n, stream)
+    if st != L.OK:
+        raise L.AnsxError(st, "ansx_generate_dev")

@@ -16,6 +16,7 @@
 #include "ansx_kernels.h"
 #include "ansx_rfold.h"
 #include "ansx_model.h"
+#include "ansx_gen.h"
 
 namespace {
 
@@ -49,6 +50,7 @@ struct ansx_ctx {
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
     std::map<u64, u32> ns_hint;
+    ansx_encode_stats last = {};
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
     // the per-call hot path never looks at the environment.
@@ -585,10 +587,16 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
             rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, ns_cap);
     }
     bool missed = false;
+    u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK ? 2u : 1u);
     if (rc == ANSX_RETRY_GENERAL) {
         missed = eligible;
+        path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
+    c->last.path = path;
+    c->last.max_nsyms = c->h_pin[ANSX_G_MAXNSYMS];
+    c->last.max_log2_frame = c->h_pin[ANSX_G_MAXLOGM];
+    c->last.near_threshold_decisions = c->h_pin[ANSX_G_NEAR];
     if (rc == ANSX_OK && !P.plain) {
         // a miss raises the hint past what was seen, so inputs whose alphabets creep upwards do not
         // miss on every call
@@ -896,6 +904,13 @@ int ansx_init(int device, ansx_ctx** out)
     return ANSX_OK;
 }
 
+int ansx_last_encode_stats(const ansx_ctx* c, ansx_encode_stats* out)
+{
+    if (!c || !out) return ANSX_ERR_ARG;
+    *out = c->last;
+    return ANSX_OK;
+}
+
 int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
 {
     if (!c || !name) return ANSX_ERR_ARG;
@@ -1033,6 +1048,93 @@ int ansx_decode(ansx_ctx* c, int kind, int f, const uint8_t* in, size_t in_bytes
     return ANSX_OK;
 }
 
+int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const size_t* part_bytes, int nparts,
+    uint8_t* d_out, size_t cap, size_t* out_bytes, void* stream)
+{
+    if (!c || !d_parts || !part_bytes || !d_out || !out_bytes || nparts < 1 || nparts > ANSX_MERGE_MAX_PARTS) return ANSX_ERR_ARG;
+    if ((uintptr_t)d_out & 15u) return ANSX_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // the part headers decide the layout: one small read-back
+    u8* hp = (u8*)c->h_pin + 64;  // 4096-byte pinned page: 63 headers fit behind the first 64 bytes
+    std::vector<ansx_container_header> H((size_t)nparts);
+    for (int i = 0; i < nparts; i += 63) {
+        const int m = std::min(63, nparts - i);
+        for (int j = 0; j < m; j++) {
+            if (!d_parts[i + j] || ((uintptr_t)d_parts[i + j] & 7u) || part_bytes[i + j] < sizeof(ansx_container_header)) return ANSX_ERR_ARG;
+            HIPCHK(c, hipMemcpyAsync(hp + 64 * j, d_parts[i + j], 64, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (int j = 0; j < m; j++) {
+            int rc = parse_header(hp + 64 * j, part_bytes[i + j], &H[(size_t)(i + j)]);
+            if (rc) return rc;
+        }
+    }
+    ansx_merge_desc D;
+    memset(&D, 0, sizeof(D));
+    u64 nblocks = 0, n = 0, pay = 0;
+    u32 maxlg = 0, maxns = 0;
+    for (int i = 0; i < nparts; i++) {
+        const ansx_container_header& h = H[(size_t)i];
+        if (h.kind != H[0].kind || h.fidelity != H[0].fidelity || h.block_ints != H[0].block_ints
+            || h.ckpt_interval != H[0].ckpt_interval || h.ckpts_per_block != H[0].ckpts_per_block)
+            return ANSX_ERR_FORMAT;
+        if (i + 1 < nparts && h.n % h.block_ints != 0) return ANSX_ERR_FORMAT;  // only the last part may end in a partial block
+        if (h.payload_offset > part_bytes[i] || h.payload_bytes > part_bytes[i] - h.payload_offset) return ANSX_ERR_FORMAT;
+        if (h.payload_offset > 0xFFFFFFFFull) return ANSX_ERR_FORMAT;
+        D.part[i].src = d_parts[i];
+        D.part[i].first_block = nblocks;
+        D.part[i].pay_base = pay;
+        D.part[i].payload_bytes = h.payload_bytes;
+        D.part[i].nblocks = h.nblocks;
+        D.part[i].payload_off = (u32)h.payload_offset;
+        nblocks += h.nblocks;
+        n += h.n;
+        pay += h.payload_bytes;
+        maxlg = std::max(maxlg, h.max_log2_frame);
+        maxns = std::max(maxns, h.max_nsyms);
+    }
+    if (nblocks > 0x7FFFFFFFull) return ANSX_ERR_ARG;
+    ansx_opts o = { H[0].block_ints, H[0].ckpt_interval ? H[0].ckpt_interval : ANSX_NO_CHECKPOINTS, 0, 0 };
+    Plan P;
+    if (make_plan((int)H[0].kind, (int)H[0].fidelity, (size_t)n, &o, &P)) return ANSX_ERR_FORMAT;
+    if (P.g.nblocks != nblocks || P.g.nckf != H[0].ckpts_per_block) return ANSX_ERR_FORMAT;
+    const u64 total = P.lay.payload_off + pay;
+    if (total > cap) return ANSX_ERR_CAPACITY;
+    D.nparts = (u32)nparts;
+    D.nckf = P.g.nckf;
+    D.ckoff_off = P.lay.ckoff_off;
+    D.ckstate_off = P.lay.ckstate_off;
+    D.payload_off = P.lay.payload_off;
+    // header, final index entry, alignment padding: written from the host image
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
+    ansx_container_header M = H[0];
+    M.n = n;
+    M.nblocks = (u32)nblocks;
+    M.max_log2_frame = maxlg;
+    M.max_nsyms = maxns;
+    M.payload_bytes = pay;
+    M.payload_offset = P.lay.payload_off;
+    memcpy(hp, &M, 64);
+    memcpy(hp + 64, &pay, 8);
+    HIPCHK(c, hipMemcpyAsync(d_out, hp, 64, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_out + 64 + 8 * nblocks, hp + 64, 8, hipMemcpyHostToDevice, s));
+    u64 max_pieces = 1;
+    for (int i = 0; i < nparts; i++) {
+        const u64 nb_ = D.part[i].nblocks;
+        const u64 pieces = (8 * nb_ + 65535) / 65536 + (4 * nb_ * D.nckf + 65535) / 65536 + (32 * nb_ * D.nckf + 65535) / 65536
+            + (D.part[i].payload_bytes + 65535) / 65536;
+        max_pieces = std::max(max_pieces, pieces);
+    }
+    prof_begin(c, "k_merge_containers", s);
+    hipLaunchKernelGGL(k_merge_containers, dim3((u32)max_pieces, (u32)nparts), dim3(256), 0, s, D, d_out);
+    prof_end(c, s);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));  // hp is reused by the next call
+    *out_bytes = (size_t)total;
+    return ANSX_OK;
+}
+
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out)
 {
     if (!container || !out) return ANSX_ERR_ARG;
@@ -1105,6 +1207,46 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
 }
 
 double ansx_host_log2(double x) { return ansx_log2_portable(x); }
+
+static int gen_setup(int dist, double a, double b, uint64_t seed, ansx_gen_params* P)
+{
+    if (dist == ANSX_GEN_UNIFORM) {
+        if (!(a >= 0.0 && a <= b && b <= 4294967295.0) || a != __builtin_floor(a) || b != __builtin_floor(b)) return ANSX_ERR_ARG;
+    } else if (dist == ANSX_GEN_GEOMETRIC) {
+        if (!(a > 0.0 && a < 1.0)) return ANSX_ERR_ARG;
+    } else if (dist == ANSX_GEN_ZIPF) {
+        if (!(a >= 1.0 && a <= 1073741823.0 && b > 0.0 && b < 64.0) || a != __builtin_floor(a)) return ANSX_ERR_ARG;
+    } else return ANSX_ERR_ARG;
+    P->dist = (u32)dist;
+    P->seed = seed;
+    P->a = a;
+    P->b = b;
+    gen_prepare(P);
+    return ANSX_OK;
+}
+
+int ansx_generate_dev(ansx_ctx* c, int dist, double a, double b, uint64_t seed, uint64_t first_index,
+    uint32_t* d_out, size_t n, void* stream)
+{
+    if (!c || !d_out || n == 0) return ANSX_ERR_ARG;
+    ansx_gen_params P;
+    int rc = gen_setup(dist, a, b, seed, &P);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    LAUNCH(c, "k_generate", k_generate, (n + 255) / 256, 256, 0, s, P, d_out, (u64)n, (u64)first_index);
+    return ANSX_OK;
+}
+
+int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t first_index, uint32_t* out, size_t n)
+{
+    if (!out || n == 0) return ANSX_ERR_ARG;
+    ansx_gen_params P;
+    int rc = gen_setup(dist, a, b, seed, &P);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) out[i] = gen_value(P, first_index + i);
+    return ANSX_OK;
+}
 
 int ansx_selftest_log2(ansx_ctx* c, const double* in, double* out, size_t n)
 {

@@ -44,7 +44,20 @@ struct __attribute__((aligned(16))) ansx_enc_entry {
     double rcp;
 };
 
-enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3 };
+enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
+    // (words 4, 5 hold the 64-bit payload size)
+    ANSX_G_NEAR = 6 };  // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
+
+// The one step of the path whose parity with the reference is empirical rather than by construction:
+// log2 is libm's there and ansx_log2_portable here (<= 1 ulp apart), so the decision XH < H * 1.001
+// (ans_util.hpp:149) could differ when the two sides agree to ~15 digits.  Every such comparison is
+// counted (expected: none, ever -- the sums differ by ~1e-3 relative or more in practice) and reported
+// through ansx_last_encode_stats, so a flip cannot go unnoticed.
+__device__ __forceinline__ bool ansx_near_threshold(double XH, double thr)
+{
+    const double d = XH - thr;
+    return (d < 0 ? -d : d) <= 1e-12 * thr;
+}
 enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 
 // ------------------------------------------------------------------------------------------
@@ -612,6 +625,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             break;
         }
         const double XH = ansx_bits_to_f64((u64)m2 | ((u64)m3 << 32));
+        if (lane == 0 && ansx_near_threshold(XH, thr)) atomicAdd(&gflags[ANSX_G_NEAR], 1u);
         if (XH < thr) {  // ans_util.hpp:149
             chosen = (int)T;
             break;
@@ -2333,4 +2347,78 @@ __global__ void k_decode(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
         dec_segments<false>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU concatenation: the rank containers of contiguous whole-block ranges become ONE
+// container.  Everything but the block index is a plain copy to a new offset; index entries are rebased
+// by the payload bytes of the parts in front.  One launch: blockIdx.y = part, blockIdx.x = 64 KiB piece.
+// ------------------------------------------------------------------------------------------
+#define ANSX_MERGE_MAX_PARTS 64
+struct ansx_merge_part {
+    const u8* src;       // the part container
+    u64 first_block;     // index of its first block in the merged container
+    u64 pay_base;        // payload bytes of the parts in front of it
+    u64 payload_bytes;
+    u32 nblocks;
+    u32 payload_off;     // inside the part
+};
+struct ansx_merge_desc {
+    ansx_merge_part part[ANSX_MERGE_MAX_PARTS];
+    u64 ckoff_off, ckstate_off, payload_off;  // merged layout (index at 64)
+    u32 nparts, nckf;
+};
+
+// dst[0..n) = src[0..n), any alignment: dword stores on the aligned body of dst, unaligned dword loads
+__device__ __forceinline__ void merge_copy(u8* __restrict__ dst, const u8* __restrict__ src, u64 n, u32 tid, u32 nt)
+{
+    u64 head = (u64)((4 - ((uintptr_t)dst & 3)) & 3);
+    if (head > n) head = n;
+    if (tid < head) dst[tid] = src[tid];
+    const u64 nd = (n - head) >> 2;
+    u32* d4 = (u32*)(dst + head);
+    const u8* s1 = src + head;
+    for (u64 j = tid; j < nd; j += nt) d4[j] = ld_u32_unaligned(s1 + 4 * j);
+    const u64 done = head + 4 * nd;
+    if (done + tid < n) dst[done + tid] = src[done + tid];
+}
+
+__global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8* __restrict__ out)
+{
+    const u32 tid = threadIdx.x;
+    const ansx_merge_part P = D.part[blockIdx.y];
+    const u64 PIECE = 65536;
+    // section sizes of this part, in the order they are walked by blockIdx.x
+    const u64 idx_bytes = 8ull * P.nblocks, cko_bytes = 4ull * P.nblocks * D.nckf, cks_bytes = 32ull * P.nblocks * D.nckf;
+    const u64 n_idx = (idx_bytes + PIECE - 1) / PIECE, n_cko = (cko_bytes + PIECE - 1) / PIECE,
+              n_cks = (cks_bytes + PIECE - 1) / PIECE, n_pay = (P.payload_bytes + PIECE - 1) / PIECE;
+    u64 piece = blockIdx.x;
+    // part layout (make_plan): index at 64, restart offsets behind the nblocks + 1 index entries
+    const u64 p_cko = 64 + 8ull * (P.nblocks + 1);
+    const u64 p_cks = (p_cko + cko_bytes + 7) / 8 * 8;
+    if (piece < n_idx) {  // block index, rebased
+        const u64* src = (const u64*)(P.src + 64);
+        u64* dst = (u64*)(out + 64) + P.first_block;
+        const u64 lo = piece * (PIECE / 8);
+        const u64 hi = lo + PIECE / 8 < P.nblocks ? lo + PIECE / 8 : P.nblocks;
+        for (u64 i = lo + tid; i < hi; i += 256) dst[i] = src[i] + P.pay_base;
+        return;
+    }
+    piece -= n_idx;
+    if (piece < n_cko) {
+        const u64 lo = piece * PIECE, len = cko_bytes - lo < PIECE ? cko_bytes - lo : PIECE;
+        merge_copy(out + D.ckoff_off + 4ull * P.first_block * D.nckf + lo, P.src + p_cko + lo, len, tid, 256);
+        return;
+    }
+    piece -= n_cko;
+    if (piece < n_cks) {
+        const u64 lo = piece * PIECE, len = cks_bytes - lo < PIECE ? cks_bytes - lo : PIECE;
+        merge_copy(out + D.ckstate_off + 32ull * P.first_block * D.nckf + lo, P.src + p_cks + lo, len, tid, 256);
+        return;
+    }
+    piece -= n_cks;
+    if (piece < n_pay) {
+        const u64 lo = piece * PIECE, len = P.payload_bytes - lo < PIECE ? P.payload_bytes - lo : PIECE;
+        merge_copy(out + D.payload_off + P.pay_base + lo, P.src + P.payload_off + lo, len, tid, 256);
+    }
 }

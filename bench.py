@@ -5,23 +5,35 @@
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[1]): ANSfold-1 on 256 Mi uint32 drawn from Zipf(s=1.2) over
-{1..2^20}, HBM-resident, per GPU (weak scaling; config 4's 2e9 ints over 8 GPUs is the same
-per-GPU size).  One step = one encode (histogram -> normalise -> prelude -> 4-state rANS -> container)
-plus one decode of the whole batch; with N > 1 every rank also ships its compressed container to
-rank 0 over RCCL (send/recv, xGMI), overlapped with its decode.  value = total ints of all ranks
-/ step time, in Mints/s.  Output is bit-exact per block against the reference CPU encoder
-(tests/test_gpu_parity.py); the round trip is verified here on every run.
+{1..2^20}, HBM-resident, per GPU (weak scaling; config 4's 2e9 ints over 8 GPUs is the same per-GPU
+size).  One step = one encode (histogram -> normalise -> prelude -> 4-state rANS -> container) plus one
+decode of the whole batch; with N > 1 every rank also ships its container to the root over RCCL
+(send/recv, xGMI) and the root concatenates them into ONE container with the library's merge kernel
+(ansx_merge_containers_dev) inside the timed step.  value = total ints of all ranks / step time, in
+Mints/s.  Output is bit-exact per block against the reference CPU encoder (tests/test_gpu_parity.py);
+the round trip is verified here on every run, and at N > 1 the merged container is decoded on the root
+after the last step and compared with the generator's values.
+
+Inputs are drawn on the device by the package's own generator kernels (ansx_generate_dev, the reference's
+distributions: src/generate_inputs.cpp, include/zipf_dist.hpp); seeds are in the JSON line.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel: algorithmic bytes (encode 4+c, decode c+4 bytes/int)
-               / its average launch duration (hipEvents inside libansx on the launch stream),
-               against the 8 TB/s HBM peak
-  cpu_baseline the reference itself (oracle/_ref, "reference") or the C restatement ("port"),
-               single thread, on a bounded sample of the same data, rank 0 at N = 1 only
+  roofline       dominant kernel: algorithmic bytes (encode 4+c, decode c+4 bytes/int) / its
+                 average launch duration (hipEvents inside libansx on the launch stream), against the
+                 8 TB/s HBM peak; `traffic` is replayed from the committed PMC summary (traffic_source)
+  cpu_baseline   the reference itself (oracle/_ref, "reference") or the C restatement ("port"), single
+                 thread, on a bounded sample of the same data, rank 0 at N = 1 only
+  extra_configs  (N = 1) the other single-GPU BASELINE configs, a few steps each: config 3 (ANSfold-3 and
+                 ANSrfold-3 on Zipf over 2^24), config 1's data shape (uniform(1..256)), and the config-5
+                 fallback (BWT-MTF ranks of a local text) -- each with round-trip check,
+                 bits/int, per-kernel times and its own roofline
 """
 import argparse
+import collections
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,33 +41,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SEED = 1234
 
 
-def gen_zipf(torch, n, log2_sigma, s, seed, device):
-    """Zipf(s) over {1..2^log2_sigma} by inverse-CDF sampling on the GPU (synthetic input;
-    torch is plumbing here, not the product)."""
-    N = 1 << log2_sigma
-    w = 1.0 / torch.arange(1, N + 1, dtype=torch.float64, device=device) ** s
-    cdf = torch.cumsum(w, 0)
-    cdf /= cdf[-1].clone()
-    g = torch.Generator(device=device).manual_seed(seed)
+def canonical_spec(spec):
+    return "uniform1-256" if spec == "uniform256" else spec  # BASELINE config 1: uniform(1..256)
+
+
+def gen_input(torch, A, ctx, spec, n, seed, device, first_index=0):
+    """Synthetic input drawn on the device by the package's generator kernels; element i is a pure
+    function of (seed, first_index + i), so rank r of N draws ITS slice of one global list."""
     out = torch.empty(n, dtype=torch.int32, device=device)
-    chunk = 1 << 25
-    for a in range(0, n, chunk):
-        m = min(chunk, n - a)
-        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
-        out[a:a + m] = (torch.searchsorted(cdf, u) + 1).clamp_(max=N).to(torch.int32)
+    A.generate_dev(ctx, canonical_spec(spec), out.data_ptr(), n, seed=seed, first_index=first_index)
+    torch.cuda.synchronize()
     return out
 
 
-def gen_uniform(torch, n, lo, hi, seed, device):
-    g = torch.Generator(device=device).manual_seed(seed)
-    return torch.randint(lo, hi + 1, (n,), generator=g, device=device, dtype=torch.int32)
-
-
-def cpu_baseline(sample, kind, f, block_ints=16384):
-    """Reference CPU path, one thread, whole-list encode()+decode() as table_efficiency.cpp
-    times it (min over runs).  Uses oracle/ strictly as the measured CPU comparator."""
+def cpu_baseline(sample, kind, f, block_ints=16384, budget_s=12.0):
+    """Reference CPU path, one thread, whole-list encode()+decode() as table_efficiency.cpp times it
+    (min over runs).  Uses oracle/ strictly as the measured CPU comparator."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
@@ -65,29 +69,35 @@ def cpu_baseline(sample, kind, f, block_ints=16384):
     runs = 3
     t_enc, t_dec = 1e30, 1e30
     stream = None
-    for _ in range(runs):
+    t_start = time.perf_counter()
+    for i in range(runs):
         t0 = time.perf_counter()
-        if use_ref:
-            stream = ol.ref_encode(kind, f, sample)
-        else:
-            stream = ol.oracle_encode(kind, f, sample)[0]
+        stream = ol.ref_encode(kind, f, sample) if use_ref else ol.oracle_encode(kind, f, sample)[0]
         t_enc = min(t_enc, time.perf_counter() - t0)
-    for _ in range(runs):
+        if time.perf_counter() - t_start > budget_s / 2:
+            runs = i + 1
+            break
+    for i in range(runs):
         t0 = time.perf_counter()
         back = ol.ref_decode(kind, f, stream, n) if use_ref else ol.oracle_decode(kind, f, stream, n)
         t_dec = min(t_dec, time.perf_counter() - t0)
     ok = bool(np.array_equal(back, sample))
-    # like-for-like row: the same data encoded/decoded block by block (one reference encode()
-    # per block_ints ints, exactly the units the GPU processes), on a slice of the sample
+    # like-for-like row: the same data encoded/decoded block by block (one reference encode() per
+    # block_ints ints, exactly the units the GPU processes), on a slice of the sample
     blk_n = min(n, 8 * (1 << 20))
     tb_enc = tb_dec = 0.0
     streams = []
+    done = 0
     for a in range(0, blk_n, block_ints):
         part = np.ascontiguousarray(sample[a:a + block_ints])
         t0 = time.perf_counter()
         s_ = ol.ref_encode(kind, f, part) if use_ref else ol.oracle_encode(kind, f, part)[0]
         tb_enc += time.perf_counter() - t0
         streams.append((s_, part.size))
+        done += part.size
+        if tb_enc > budget_s / 3:  # (ANSrfold's reference encoder sorts a (max value + 1)-entry vector per call)
+            break
+    blk_n = done
     for s_, m in streams:
         t0 = time.perf_counter()
         _ = ol.ref_decode(kind, f, s_, m) if use_ref else ol.oracle_decode(kind, f, s_, m)
@@ -100,6 +110,8 @@ def cpu_baseline(sample, kind, f, block_ints=16384):
         "blocked": blocked,
         "value": n / (t_enc + t_dec) / 1e6, "unit": "Mints/s", "cores": 1,
         "kind": "reference" if use_ref else "port",
+        "build": ("oracle/_ref: unmodified reference headers, clang++ -O3 -ffp-contract=off, no -march=native "
+                  "(built in the authoring container, executed here)") if use_ref else "oracle/ans_oracle.c, gcc -O3",
         "sample": "first %d ints of the workload, one whole-list encode()+decode(), min of %d runs" % (n, runs),
         "enc_mints": n / t_enc / 1e6, "dec_mints": n / t_dec / 1e6,
         "bits_per_int": 8.0 * stream.size / n, "roundtrip_ok": ok,
@@ -107,30 +119,27 @@ def cpu_baseline(sample, kind, f, block_ints=16384):
     }
 
 
-def pmc_traffic(kernel, args, n):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate
-    passes, gfx950 correction calibrated on k_fold_hist).  Counters cannot be read from inside
-    this process, so the figure is only reported when the workload is the profiled one."""
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes, gfx950
+    correction calibrated on k_fold_hist).  Counters cannot be read from inside this process, so the
+    figure is REPLAYED from that file and only when its workload string is this run's; returns
+    (bytes, source) or (None, reason)."""
     try:
-        import glob
-
-        best = None
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json"))):
-            with open(path) as fh:
-                best = json.load(fh)
-        if best is None:
-            return None
-        want = "ANS%s-%d, %d ints, %s, block %d, ckpt %d" % (args.codec, args.fidelity, n, args.dist,
-                                                              args.block or 16384, args.ckpt or 1024)
-        if best.get("workload") != want:
-            return None
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
+        if not paths:
+            return None, "no PMC summary under profiles/"
+        with open(paths[-1]) as fh:
+            best = json.load(fh)
+        rel = os.path.relpath(paths[-1], ROOT)
+        if best.get("workload") != workload:
+            return None, "%s profiles a different workload (%s)" % (rel, best.get("workload"))
         for name, v in best["kernels"].items():
             if name.split("<")[0] == kernel:
-                return v["hbm_bytes"]
-    except Exception:
-        return None
-    return None
+                return v["hbm_bytes"], "replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
+        return None, "%s has no entry for %s" % (rel, kernel)
+    except Exception as exc:  # noqa: BLE001
+        return None, "unreadable PMC summary: %r" % (exc,)
 
 
 def _cpu_model():
@@ -144,6 +153,114 @@ def _cpu_model():
     return "unknown"
 
 
+def kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload, reps=3):
+    """Per-kernel hipEvent timing pass (outside the timed region) -> (kernels, roofline)."""
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(reps):
+        nbp = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+        codec.decode_dev(d_out.data_ptr(), nbp, d_back.data_ptr(), n, stream=stream)
+    torch.cuda.synchronize()
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    kernels = {name: {"avg_ms": ms / max(cnt, 1), "launches_per_step": cnt / reps} for name, ms, cnt in prof}
+    per_step = {name: ms / reps for name, ms, cnt in prof}
+    dom = max(per_step, key=per_step.get)
+    avg_ms = kernels[dom]["avg_ms"]
+    # algorithmic bytes per launch (SURVEY 8d): the encoder reads 4 B/int and writes c, the decoder
+    # reads c and writes 4; other kernels are priced by what they must touch
+    enc, dec = (4 + c_bytes) * n, (c_bytes + 4) * n
+    alg = {"k_encode": enc, "k_encode_gtab": enc, "k_decode": dec, "k_decode_gtab": dec, "k_decode_table": dec,
+           "k_fold_hist": 4.0 * n, "k_model_fused": 4.0 * n, "k_compact": 2 * c_bytes * n,
+           "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    traffic, source = pmc_traffic(dom, workload)
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms}
+    return kernels, roofline
+
+
+def workload_string(codec_name, f, n, spec, block, ckpt):
+    return "ANS%s-%d, %d ints, %s, block %d, ckpt %d" % (codec_name, f, n, spec, block, ckpt)
+
+
+def run_single(torch, A, ctx, device, codec_name, fidelity, spec, n, steps, warmup, block=0, ckpt=0, d_in=None,
+               seed=SEED, cpu_sample=0):
+    """One single-GPU configuration: timed encode+decode steps, round trip, per-kernel pass."""
+    cls = A.ANSfold if codec_name == "fold" else A.ANSrfold
+    codec = cls(fidelity, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    if d_in is None:
+        d_in = gen_input(torch, A, ctx, spec, n, seed, device)
+    cap = min(codec.bound(n), 8 * n + (64 << 20))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+    d_back = torch.zeros(n, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    nb = 0
+    for _ in range(warmup):
+        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(d_back, d_in))
+    stats = ctx.last_encode_stats()
+    c_bytes = nb / n
+    workload = workload_string(codec_name, fidelity, n, spec, block or A.DEFAULT_BLOCK_INTS, ckpt or A.DEFAULT_CKPT_INTERVAL)
+    kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
+    res = {"workload": workload, "codec": codec.name(), "distribution": spec, "ints": n, "seed": seed,
+           "value": n * steps / dt / 1e6, "unit": "Mints/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "roundtrip_ok": ok, "bits_per_int": 8 * c_bytes, "near_threshold_decisions": stats["near_threshold_decisions"],
+           "encode_path": stats["path"], "roofline": roofline, "kernels": kernels}
+    if cpu_sample:
+        kind = A.FOLD if codec_name == "fold" else A.RFOLD
+        sample = d_in[:min(n, cpu_sample)].cpu().numpy().view("uint32")
+        res["cpu_baseline"] = cpu_baseline(sample, kind, fidelity, block or A.DEFAULT_BLOCK_INTS, budget_s=6.0)
+        res["speedup_vs_cpu_1thread"] = res["value"] / res["cpu_baseline"]["value"]
+    del d_out, d_back
+    return res
+
+
+def bwtmtf_ranks(max_words=8 * (1 << 20)):
+    """Config 5 fallback: BWT-MTF ranks of a local text, made by the package's own
+    generate_bwtmtf tool (the reference's src/generate_bwtmtf.cpp pipeline) from the Python standard
+    library's sources of this image (English prose + code, a deterministic file list)."""
+    import numpy as np
+
+    tools = os.path.join(ROOT, "ans_large_alphabet_amd", "tools")
+    exe = os.path.join(tools, "generate_bwtmtf.x")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", tools, "generate_bwtmtf.x"])
+    files = sorted(glob.glob("/usr/lib/python3.10/**/*.py", recursive=True))
+    files += sorted(glob.glob("/usr/local/lib/python3.10/dist-packages/torch/**/*.py", recursive=True))
+    if not files:
+        return None, "no local text found"
+    tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ansx_bwtmtf_%d" % os.getuid())
+    os.makedirs(tmp, exist_ok=True)
+    corpus = os.path.join(tmp, "corpus.txt")
+    total = 0
+    with open(corpus, "wb") as out:
+        for f in files:
+            try:
+                with open(f, "rb") as fh:
+                    b = fh.read()
+            except OSError:
+                continue
+            out.write(b)
+            total += len(b)
+            if total > 6 * max_words:  # ~6 bytes per word
+                break
+    subprocess.check_call([exe, "-i", corpus, "-n", str(max_words), "-w", "-o", os.path.join(tmp, "pylib")],
+                          stdout=subprocess.DEVNULL)
+    ranks = np.fromfile(os.path.join(tmp, "pylib-WORD-BWTMTF.u32"), dtype=np.uint32)
+    return ranks, ("word-parsed BWT-MTF ranks of the first %d bytes of this image's Python sources (/usr/lib/python3.10, "
+                   "then torch), tools/generate_bwtmtf.x" % total)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,15 +269,16 @@ def main():
     ap.add_argument("--n", "--ints", dest="n", type=int, default=256 * (1 << 20), help="ints per GPU")
     ap.add_argument("--codec", default="fold", choices=["fold", "rfold"])
     ap.add_argument("--fidelity", type=int, default=1)
-    ap.add_argument("--dist", default="zipf20s1.2", help="zipf<log2 sigma>s<exponent> | uniform256")
+    ap.add_argument("--dist", default="zipf20s1.2", help="zipf<log2 n>[s<q>] | uniform<lo>-<hi> | uniform256 | geom<p>")
     ap.add_argument("--block", type=int, default=0, help="ints per block (0 = library default)")
     ap.add_argument("--ckpt", type=int, default=0, help="restart interval (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64 * (1 << 20))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--gather-root", default="rotate", choices=["rotate", "fixed"],
-                    help="N > 1: root of the per-step container gather: rank k mod N of step k (default; "
-                         "spreads the traffic over all xGMI links) or always rank 0")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs rows (N = 1)")
+    ap.add_argument("--gather-root", default="fixed", choices=["fixed", "rotate"],
+                    help="N > 1: root of the per-step container gather: always rank 0 (default) or rank k mod N "
+                         "of step k (spreads the traffic over all xGMI links)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N > 1 control-flow rehearsal on ONE GPU: gloo backend, every rank on cuda:0, "
                          "containers gathered through host copies (not a measurement)")
@@ -187,6 +305,7 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)  # RCCL on ROCm
+    cdev = "cpu" if args.rehearse_gloo else device  # where control-plane tensors of the collectives live
 
     import ans_large_alphabet_amd as A
 
@@ -195,24 +314,13 @@ def main():
     codec = cls(args.fidelity, ctx=ctx, block_ints=args.block, ckpt_interval=args.ckpt)
     kind = A.FOLD if args.codec == "fold" else A.RFOLD
     n = args.n
+    block_ints = args.block or A.DEFAULT_BLOCK_INTS
+    if world > 1 and n % block_ints:
+        raise SystemExit("N > 1: ints per GPU must be a multiple of the block size (whole blocks per rank)")
 
-    # ---- synthetic input, resident in HBM
-    if args.dist.startswith("zipf"):
-        lg, s = args.dist[4:].split("s")
-        d_in = gen_zipf(torch, n, int(lg), float(s), 1234 + rank, device)
-    elif args.dist == "uniform256":
-        d_in = gen_uniform(torch, n, 1, 256, 1234 + rank, device)
-    else:
-        raise SystemExit("unknown --dist")
+    # ---- synthetic input, resident in HBM: rank r holds ints [r n, (r+1) n) of ONE global list
+    d_in = gen_input(torch, A, ctx, args.dist, n, SEED, device, first_index=rank * n)
     cap = min(codec.bound(n), 8 * n + (64 << 20))
-    # N > 1.  Every step ends with the rank containers concatenated on ONE GPU (RCCL send/recv: each
-    # sender uses its direct xGMI link to the root).  A rank's container is ~0.29 GB, i.e. several ms
-    # on one link -- longer than the step's compute -- so (1) the transfer of step k overlaps the
-    # decode of step k and the following encodes (DEPTH container buffers; a buffer is reused only
-    # after the transfer that reads it has been waited for), (2) the root rotates (rank k mod N), so
-    # consecutive steps use different links / directions instead of funnelling everything into rank
-    # 0's seven links, and (3) each pipeline slot has its own communicator, because groups issued on
-    # one communicator execute back to back on its stream.
     rotate = world > 1 and args.gather_root == "rotate"
     DEPTH = 1 if world == 1 else (min(4, max(2, world)) if rotate else 2)
     outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(DEPTH)]
@@ -220,35 +328,47 @@ def main():
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
 
-    from ans_large_alphabet_amd import dist as adist
-    import collections
-
+    # N > 1.  Every step ends with the rank containers concatenated into one container on a root GPU.
+    # A rank's container is ~0.29 GB, i.e. several ms on one xGMI link -- longer than the step's compute
+    # -- so the transfer of step k overlaps the decode of step k and the following encode (DEPTH buffers;
+    # a buffer is reused only after the transfer that reads it has been waited for).  Transfers have a
+    # FIXED size agreed once before the timed region (largest warm-up container + slack: the true size is
+    # in the container header), so no per-step size exchange or host read-back sits on the path; the root
+    # merges with ansx_merge_containers_dev when the step's transfers have landed.
     groups = [None] * DEPTH
+    setup_ok = 1
     if dist is not None and rotate:
         try:
             groups = [dist.new_group(ranks=list(range(world))) for _ in range(DEPTH)]
-            # establish every (communicator, root) connection before anything is timed
-            tiny = torch.zeros(64, dtype=torch.uint8, device="cpu" if args.rehearse_gloo else device)
-            for g_ in groups:
-                for d_ in range(world):
-                    adist.gather_containers(tiny, 64, dst=d_, group=g_, async_op=False)
-            if not args.rehearse_gloo:
-                torch.cuda.synchronize()
-        except Exception as exc:  # same code on every rank: a setup failure is symmetric
-            if rank == 0:
-                print("bench.py: rotating-root setup failed (%r); using the fixed root" % (exc,), file=sys.stderr)
+        except Exception as exc:  # noqa: BLE001
+            print("bench.py rank %d: rotating-root setup failed (%r)" % (rank, exc), file=sys.stderr)
+            setup_ok = 0
+    if dist is not None:
+        # a setup failure on ANY rank sends EVERY rank to the fixed root (ranks must not diverge)
+        flag = torch.tensor([setup_ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and rotate:
             rotate = False
             DEPTH = 2
             outs = outs[:2]
             groups = [None] * DEPTH
 
-    state = {"k": 0}
-    pending = collections.deque()  # (works, receive buffer kept alive) of the steps still in flight
+    state = {"k": 0, "xfer": 0, "merged_bytes": 0}
+    pending = collections.deque()  # (step, root, works, slot) of the steps still in flight
+    recv = {}                      # per pipeline slot on a root: receive buffer [world][xfer]
+    merged = [None]
 
-    def drain_one():
-        works, _keep = pending.popleft()
+    def finish_one():
+        k, root, works, slot = pending.popleft()
         for w in works:
             w.wait()
+        if rank == root and world > 1 and state["xfer"]:
+            buf = recv[slot]
+            x = state["xfer"]
+            if args.rehearse_gloo:
+                buf = buf.to(device)
+            ptrs = [buf.data_ptr() + r * x for r in range(world)]
+            state["merged_bytes"] = ctx.merge_containers_dev(ptrs, [x] * world, merged[0].data_ptr(), merged[0].numel())
 
     def step():
         k = state["k"]
@@ -256,30 +376,59 @@ def main():
         slot = k % DEPTH
         out = outs[slot]
         nb = codec.encode_dev(d_in.data_ptr(), n, out.data_ptr(), cap, stream=stream)
-        works, buf = [], None
-        if dist is not None:
-            src = out[:nb].cpu() if args.rehearse_gloo else out
-            buf, _sizes, works = adist.gather_containers(src, nb, dst=(k % world) if rotate else 0,
-                                                         group=groups[slot], async_op=True)
+        works, root = [], 0
+        if dist is not None and state["xfer"]:
+            root = (k % world) if rotate else 0
+            x = state["xfer"]
+            if nb > x:
+                raise SystemExit("container outgrew the agreed transfer size")
+            src = out[:x].cpu() if args.rehearse_gloo else out[:x]
+            if rank == root:
+                buf = recv[slot]
+                buf[rank * x:(rank + 1) * x].copy_(src)
+                ops = [dist.P2POp(dist.irecv, buf[r * x:(r + 1) * x], r, groups[slot]) for r in range(world) if r != root]
+            else:
+                ops = [dist.P2POp(dist.isend, src, root, groups[slot])]
+            works = dist.batch_isend_irecv(ops) if ops else []
         codec.decode_dev(out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
-        pending.append((works, buf))
+        pending.append((k, root, works, slot))
         while len(pending) > DEPTH - 1:  # the next user of a buffer must find its transfer finished
-            drain_one()
+            finish_one()
         return nb
 
-    def drain():
-        while pending:
-            drain_one()
-
     def sync_all():
-        drain()
+        while pending:
+            finish_one()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    nb = 0
-    for _ in range(args.warmup):
+    nb = step()  # first warm-up step: also learns the alphabet hint and, at N > 1, the transfer size
+    sync_all()
+    if dist is not None:
+        t = torch.tensor([nb], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        x = int(t.item())
+        x = min(cap, (x + x // 32 + 4096 + 15) // 16 * 16)
+        state["xfer"] = x
+        roots = range(world) if rotate else [0]
+        if rank in roots:
+            for slot in range(DEPTH):
+                recv[slot] = torch.zeros(world * x, dtype=torch.uint8, device=cdev)
+            merged[0] = torch.zeros(world * x + (1 << 20), dtype=torch.uint8, device=device)
+        if rotate and not args.rehearse_gloo:  # establish every (communicator, root) connection before timing
+            tiny = torch.zeros(64, dtype=torch.uint8, device=device)
+            for g_ in groups:
+                for d_ in range(world):
+                    if rank == d_:
+                        ops = [dist.P2POp(dist.irecv, tiny.clone(), r, g_) for r in range(world) if r != d_]
+                    else:
+                        ops = [dist.P2POp(dist.isend, tiny, d_, g_)]
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+            torch.cuda.synchronize()
+    for _ in range(max(args.warmup - 1, 1 if dist is not None else 0)):
         nb = step()
     sync_all()
     t0 = time.perf_counter()
@@ -288,45 +437,75 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ok = bool(torch.equal(d_back, d_in))
+    merged_ok = None
+    if dist is not None:
+        # the root of the LAST step decodes the merged container and checks it against the generator
+        last_root = ((state["k"] - 1) % world) if rotate else 0
+        mine = True
+        if rank == last_root:
+            total = world * n
+            whole = torch.empty(total, dtype=torch.int32, device=device)
+            codec.decode_dev(merged[0].data_ptr(), state["merged_bytes"], whole.data_ptr(), total, stream=stream)
+            torch.cuda.synchronize()
+            for r in sorted(set([0, world // 2, world - 1])):
+                want = gen_input(torch, A, ctx, args.dist, n, SEED, device, first_index=r * n)
+                mine = mine and bool(torch.equal(whole[r * n:(r + 1) * n], want))
+            del whole
+        mo = torch.tensor([1 if mine else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(mo, op=dist.ReduceOp.MIN)
+        merged_ok = bool(int(mo.item()))
+        ok = ok and merged_ok
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt / 1e6
     c_bytes = nb / n  # compressed bytes per int, everything included
+    stats = ctx.last_encode_stats()
+    workload = workload_string(args.codec, args.fidelity, n, args.dist, block_ints, args.ckpt or A.DEFAULT_CKPT_INTERVAL)
 
     # ---- per-kernel timing pass (separate from the timed region) -> roofline of the dominant kernel
-    roofline = None
-    kernels = None
+    roofline = kernels = None
     if not args.no_profile:
-        ctx.profile(True)
-        ctx.profile_reset()
-        reps = 3
-        for _ in range(reps):
-            nbp = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
-            codec.decode_dev(d_out.data_ptr(), nbp, d_back.data_ptr(), n, stream=stream)
-        torch.cuda.synchronize()
-        prof = ctx.profile_get()
-        ctx.profile(False)
-        kernels = {name: {"avg_ms": ms / max(cnt, 1), "launches_per_step": cnt / reps} for name, ms, cnt in prof}
-        per_step = {name: ms / reps for name, ms, cnt in prof}
-        dom = max(per_step, key=per_step.get)
-        avg_ms = kernels[dom]["avg_ms"]
-        # algorithmic bytes per launch: the encoder reads 4 B/int and writes c,
-        # the decoder reads c and writes 4; other kernels are priced by what they must touch
-        alg = {"k_encode": (4 + c_bytes) * n, "k_encode_gtab": (4 + c_bytes) * n, "k_decode": (c_bytes + 4) * n, "k_decode_gtab": (c_bytes + 4) * n, "k_decode_table": (c_bytes + 4) * n,
-               "k_fold_hist": 4.0 * n, "k_compact": 2 * c_bytes * n, "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
-        achieved = alg / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args, n),
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms}
+        kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         m = min(n, args.cpu_sample)
         sample = d_in[:m].cpu().numpy().view("uint32")
-        cpu = cpu_baseline(sample, kind, args.fidelity, args.block or A.DEFAULT_BLOCK_INTS)
+        cpu = cpu_baseline(sample, kind, args.fidelity, block_ints)
+
+    # ---- the other single-GPU BASELINE configs, a few steps each (N = 1 only)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        del outs, d_out, d_back, d_in
+        torch.cuda.empty_cache()
+        extra = []
+        rows = [("config 3a", "fold", 3, "zipf24s1.2", n), ("config 3b", "rfold", 3, "zipf24s1.2", n),
+                ("config 1 data shape", "fold", 1, "uniform1-256", n)]
+        for label, cn, f, spec, m in rows:
+            try:
+                r = run_single(torch, A, ctx, device, cn, f, spec, m, 3, 1,
+                               cpu_sample=0 if args.no_cpu else 16 * (1 << 20))
+                r["baseline_config"] = label
+                extra.append(r)
+            except Exception as exc:  # noqa: BLE001
+                extra.append({"baseline_config": label, "error": repr(exc)})
+            torch.cuda.empty_cache()
+        try:
+            ranks, src = bwtmtf_ranks()
+            if ranks is None:
+                extra.append({"baseline_config": "config 5 fallback", "error": src})
+            else:
+                d5 = torch.from_numpy(ranks.view("int32")).to(device)
+                r = run_single(torch, A, ctx, device, "fold", 1, "bwtmtf-pylib", ranks.size, 5, 2, d_in=d5,
+                               cpu_sample=0 if args.no_cpu else ranks.size)
+                r["baseline_config"] = "config 5 fallback (the real datasets are not in the image)"
+                r["source"] = src
+                extra.append(r)
+        except Exception as exc:  # noqa: BLE001
+            extra.append({"baseline_config": "config 5 fallback", "error": repr(exc)})
 
     if rank == 0:
         line = {
@@ -336,16 +515,21 @@ def main():
             "vs_baseline": None, "dtype": "u32 symbols / u64 ANS states (f64 only in model normalisation)",
             "data": "synthetic",
             "config": {"workload": "ANS%s-%d on %d uint32 per GPU, %s, blocks of %d ints, restart every %d"
-                                   % (args.codec, args.fidelity, n, args.dist,
-                                      args.block or A.DEFAULT_BLOCK_INTS, args.ckpt or A.DEFAULT_CKPT_INTERVAL),
+                                   % (args.codec, args.fidelity, n, args.dist, block_ints,
+                                      args.ckpt or A.DEFAULT_CKPT_INTERVAL),
                        "ints_per_gpu": n, "distribution": args.dist, "codec": codec.name(),
-                       "block_ints": args.block or A.DEFAULT_BLOCK_INTS,
-                       "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
-                       "multi_gpu": ("contiguous block ranges per rank; per-step RCCL send/recv gather of the rank containers to "
-                                     + ("a root that rotates per step (k mod N), %d transfers in flight on %d communicators" % (DEPTH - 1, DEPTH)
-                                        if rotate else "rank 0, overlapped with the next step")) if world > 1 else "single GPU"},
-            "roundtrip_ok": ok, "compressed_bytes_per_int": c_bytes, "bits_per_int": 8 * c_bytes,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+                       "generator": "ansx_generate_dev (counter-based, seed %d, rank r draws indices [r n, (r+1) n))" % SEED,
+                       "block_ints": block_ints, "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
+                       "multi_gpu": ("contiguous block ranges per rank; per step every rank sends its container (fixed %d-byte "
+                                     "transfers, RCCL send/recv) to %s, which merges them into one container with "
+                                     "ansx_merge_containers_dev inside the timed step (%d transfers in flight); the merged "
+                                     "container of the last step is decoded on its root and checked against the generator"
+                                     % (state["xfer"], "a root that rotates per step (k mod N)" if rotate else "rank 0", DEPTH - 1))
+                       if world > 1 else "single GPU"},
+            "roundtrip_ok": ok, "merged_container_ok": merged_ok,
+            "compressed_bytes_per_int": c_bytes, "bits_per_int": 8 * c_bytes,
+            "near_threshold_decisions": stats["near_threshold_decisions"], "encode_path": stats["path"],
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "extra_configs": extra,
             "workspace_mb": ctx.workspace_bytes() / 1e6,
         }
         if cpu:

@@ -134,6 +134,17 @@ int ansx_encode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint32_t* d_in,
 int ansx_decode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* d_in, size_t in_bytes,
     uint32_t* d_out, size_t n, const ansx_opts* opts, void* stream);
 
+/* Multi-GPU concatenation (the path shards by contiguous ranges of whole blocks, one container per
+ * GPU; the reference is single-threaded and has no counterpart -- its per-block calls in
+ * src/pseudo_adaptive.cpp:77-130 are the unit that is sharded).  d_parts[i] (8-byte aligned DEVICE
+ * pointers, HOST array) are `nparts` <= 64 containers of the same codec / block_ints / ckpt_interval, in
+ * list order, every one but the last holding whole blocks only; part_bytes[i] bounds each.  Writes ONE
+ * container over all their blocks to d_out (16-byte aligned device memory, which must not overlap the
+ * parts): index entries rebased, restart points and payload copied by one HIP kernel.  ansx_decode_dev
+ * on the result returns the concatenated list. */
+int ansx_merge_containers_dev(ansx_ctx* ctx, const uint8_t* const* d_parts, const size_t* part_bytes, int nparts,
+    uint8_t* d_out, size_t out_capacity, size_t* out_bytes, void* stream);
+
 /* Parse + validate a container header held in HOST memory. */
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out);
 
@@ -141,6 +152,37 @@ int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_h
 int ansx_profile_enable(ansx_ctx* ctx, int on);
 int ansx_profile_reset(ansx_ctx* ctx);
 int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int* count);
+
+/* Facts about the context's most recent ansx_encode / ansx_encode_dev call.
+ *   near_threshold_decisions  frame-size stop-rule comparisons XH < 1.001 H (ans_util.hpp:149) whose two sides
+ *                             agreed to 1e-12 relative.  The reference evaluates log2 with libm, this library
+ *                             with its own portable log2 (<= 1 ulp apart): such a comparison is the only place
+ *                             where the two could decide differently.  Expected to be 0, always; a non-zero
+ *                             value marks an output whose bit-parity with the reference is not guaranteed.
+ *   path                      0 discovery (alphabet size read back mid-call), 1 launched back to back on the
+ *                             context's alphabet hint, 2 the same with the fused model kernel; + 16: the hint
+ *                             did not hold and the call was repeated on the discovery path */
+typedef struct {
+    uint32_t max_nsyms;
+    uint32_t max_log2_frame;
+    uint32_t near_threshold_decisions;
+    uint32_t path;
+} ansx_encode_stats;
+int ansx_last_encode_stats(const ansx_ctx* ctx, ansx_encode_stats* out);
+
+/* Synthetic inputs of the reference's benchmark harness (src/generate_inputs.cpp:94-122, include/
+ * zipf_dist.hpp:49-59) as counter-based generators: element i is a pure function of (seed, first_index + i),
+ * so a list can be produced in pieces, on any number of GPUs, or on the host, with identical values.
+ *   ANSX_GEN_UNIFORM    a = lo, b = hi (inclusive)            std::uniform_int_distribution
+ *   ANSX_GEN_GEOMETRIC  a = p                                 std::geometric_distribution (failures before a success)
+ *   ANSX_GEN_ZIPF       a = n (values 1..n), b = exponent q   zipf_distribution (rejection-inversion)
+ * The distributions are the reference's; the random stream is not (std::mt19937 + libstdc++ + libm cannot be
+ * reproduced bit for bit on a GPU).  ansx_generate_dev writes to device memory on `stream` (NULL = the
+ * context's stream) and returns without synchronising; ansx_generate_host is the same function on the CPU. */
+typedef enum { ANSX_GEN_UNIFORM = 0, ANSX_GEN_GEOMETRIC = 1, ANSX_GEN_ZIPF = 2 } ansx_gen_dist;
+int ansx_generate_dev(ansx_ctx* ctx, int dist, double a, double b, uint64_t seed, uint64_t first_index,
+    uint32_t* d_out, size_t n, void* stream);
+int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t first_index, uint32_t* out, size_t n);
 
 /* Test / experiment hook: select one of the equivalent internal code paths (all must produce identical
  * bytes).  Names are those of the environment variables read once by ansx_init: ANSX_DECODE_MODE

@@ -58,11 +58,13 @@ def test_layout_matches_python_container(oracle_built):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gather_and_merge(tmp_path, oracle_built):
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_gather_and_merge(tmp_path, oracle_built, world):
+    """world 3: 18 blocks over 3 ranks, the last rank ends in a partial block."""
     port = _free_port()
     out = tmp_path / "result.txt"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(HERE, "dist_worker.py"), str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)

@@ -389,6 +389,42 @@ def test_rank_shards_merge_into_one_decodable_container(A, ctx):
     assert np.array_equal(codec.decode(merged, n), data)
 
 
+@pytest.mark.parametrize("kind,f,block,ckpt,world", [(ol.FOLD, 1, 16384, 1024, 2), (ol.FOLD, 1, 4096, 512, 3),
+                                                      (ol.RFOLD, 3, 4096, 0, 5), (ol.MSB, 0, 1024, 256, 8)])
+def test_native_merge_equals_whole_encode(A, ctx, kind, f, block, ckpt, world):
+    """ansx_merge_containers_dev (one HIP kernel on the root) on rank containers in device memory:
+    byte-identical to encoding the whole list at once, for several geometries and rank counts (the
+    last rank holds a partial block, parts sit at unaligned payload offsets)."""
+    torch = pytest.importorskip("torch")
+    from ans_large_alphabet_amd import dist as adist
+
+    n = 37 * block + 777
+    data = ol.gen_inputs("zipf20s1.2", n, seed=19)
+    codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ckpt if ckpt else A.NO_CHECKPOINTS)
+    bufs, ptrs, sizes = [], [], []
+    for r in range(world):
+        lo, cnt = adist.shard_blocks(n, block, r, world)
+        c = codec.encode(data[lo:lo + cnt])
+        t = torch.zeros(c.size + 64, dtype=torch.uint8, device="cuda")
+        t[:c.size] = torch.from_numpy(c.copy()).cuda()
+        bufs.append(t)
+        ptrs.append(t.data_ptr())
+        sizes.append(c.size)
+    whole = codec.encode(data)
+    out = torch.zeros(whole.size + 4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    nb = ctx.merge_containers_dev(ptrs, sizes, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    assert nb == whole.size
+    assert np.array_equal(out[:nb].cpu().numpy(), whole)
+    # refused: capacity, mismatching geometry, a partial block that is not last
+    with pytest.raises(A.AnsxError):
+        ctx.merge_containers_dev(ptrs, sizes, out.data_ptr(), whole.size - 1)
+    if world >= 2:
+        with pytest.raises(A.AnsxError):
+            ctx.merge_containers_dev(ptrs[::-1], sizes[::-1], out.data_ptr(), out.numel())
+
+
 def test_corrupted_payload_never_faults(A, ctx):
     """Random byte corruption anywhere in the container: the decoder must either report
     ANSX_ERR_FORMAT or return (wrong) data — never fault — and the context stays usable."""
@@ -678,3 +714,63 @@ def test_fused_model_many_geometries(A, oracle_built):
                 check_container(A, cont, d, kind, f, block, ckpt)
                 assert np.array_equal(codec.decode(cont, d.size), d), (block, fam, kind)
     c.close()
+
+
+def test_bwtmtf_fixture_blocks_and_whole_list(A, ctx):
+    """Config 5 fallback: BWT-MTF ranks of a local text (tests/golden/bwtmtf.u32, made by
+    tools/generate_bwtmtf.x); expected streams were produced by the real reference (oracle/_ref)."""
+    with open(os.path.join(GOLD, "bwtmtf.json")) as fh:
+        meta = json.load(fh)
+    data = np.fromfile(os.path.join(GOLD, "bwtmtf.u32"), dtype=np.uint32)
+    assert hashlib.sha256(data.tobytes()).hexdigest() == meta["input_sha256"]
+    for kind_name, f in (("fold", 1), ("fold", 5), ("rfold", 1)):
+        kind = ol.FOLD if kind_name == "fold" else ol.RFOLD
+        want = {(e["first"], e["n"]): e for e in meta["streams"] if e["kind"] == kind_name and e["f"] == f}
+        whole = codec_for(A, ctx, kind, f, block_ints=A.SINGLE_STREAM).encode(data)
+        e = want[(0, data.size)]
+        assert whole.size == e["stream_len"] and hashlib.sha256(whole.tobytes()).hexdigest() == e["stream_sha256"]
+        codec = codec_for(A, ctx, kind, f, block_ints=16384, ckpt_interval=1024)
+        cont = codec.encode(data)
+        parts = A.parse_container(cont)
+        for b, stream in enumerate(parts["streams"]):
+            e = want[(b * 16384, min(16384, data.size - b * 16384))]
+            assert stream.size == e["stream_len"], (kind_name, f, b)
+            assert hashlib.sha256(stream.tobytes()).hexdigest() == e["stream_sha256"], (kind_name, f, b)
+        assert np.array_equal(codec.decode(cont, data.size), data)
+    st = ctx.last_encode_stats()
+    assert st["near_threshold_decisions"] == 0 and st["max_nsyms"] > 0
+
+
+@pytest.mark.parametrize("kind,f,spec", [(ol.FOLD, 3, "zipf24s1.2"), (ol.RFOLD, 3, "zipf24s1.2"), (ol.FOLD, 1, "uniform1-256")])
+def test_full_size_configs_roundtrip_and_spot_blocks(A, ctx, kind, f, spec):
+    """BASELINE configs 3 (ANSfold-3 / ANSrfold-3 on Zipf over 2^24) and 1's data shape at a size where
+    only properties can be checked everywhere: device round trip of the whole list, container header
+    sanity, and 24 blocks spread over the list byte-compared with the oracle (streams + restart points)."""
+    import torch
+
+    n = 64 * (1 << 20) + 12345
+    d_in = torch.empty(n, dtype=torch.int32, device="cuda")
+    A.generate_dev(ctx, spec, d_in.data_ptr(), n, seed=2024)
+    codec = codec_for(A, ctx, kind, f, block_ints=16384, ckpt_interval=1024)
+    cap = codec.bound(n)
+    d_out = torch.empty(min(cap, 8 * n + (64 << 20)), dtype=torch.uint8, device="cuda")
+    d_back = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel())
+    codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n)
+    assert bool(torch.equal(d_back, d_in))
+    assert ctx.last_encode_stats()["near_threshold_decisions"] == 0
+    parts = A.parse_container(d_out[:nb].cpu().numpy())
+    H = parts["header"]
+    nblocks = (n + 16383) // 16384
+    assert H.n == n and H.nblocks == nblocks and H.payload_offset + H.payload_bytes == nb
+    assert np.all(np.diff(parts["block_off"].astype(np.int64)) > 0)
+    rng = np.random.default_rng(1)
+    picks = sorted(set([0, nblocks - 1, nblocks - 2] + [int(x) for x in rng.integers(0, nblocks, 21)]))
+    for b in picks:
+        lo, hi = b * 16384, min(n, (b + 1) * 16384)
+        blk = d_in[lo:hi].cpu().numpy().view(np.uint32)
+        exp, info, st, off = ol.oracle_encode(kind, f, blk, ckpt_interval=1024)
+        assert np.array_equal(parts["streams"][b], exp), (spec, b)
+        k = st.shape[0]
+        assert np.array_equal(parts["ckpt_off"][b][:k], off) and np.array_equal(parts["ckpt_state"][b][:k], st), (spec, b)

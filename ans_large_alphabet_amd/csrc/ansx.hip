@@ -58,6 +58,7 @@ struct ansx_ctx {
         bool table16_fixup = false;   // ANSX_TEST_TABLE16_FIXUP: integer-state encoder fed by k_table16_from32
         bool encode_gtab16 = false;   // ANSX_ENCODE_GTAB16: force the 16-byte-entry integer-state encoder
         bool parse_generic = false;   // ANSX_PARSE_GENERIC: generic prelude parser kernel
+        bool parse_win = false;       // ANSX_PARSE_WIN: the windowed parser even where the E-array fast loop applies
         bool decode_table = false;    // ANSX_DECODE_TABLE: slot -> symbol decoder tables
         bool no_stream_lds = false;   // ANSX_NO_STREAM_LDS: staged decoder reads the stream from HBM
         int decode_mode = 0;          // ANSX_DECODE_MODE: 0 auto, 1 "ring", 2 "staged"
@@ -617,21 +618,36 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     int rc;
     if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
     if ((rc = ensure(c, c->dec_info, (size_t)g.nblocks * 16))) return rc;
-    // K7: one lane per block, 64 blocks per wave.  Fast item loop when the interpolative values fit
-    // 16 bits and the per-lane arrays fit LDS (see k_parse_prelude_fast), generic loop otherwise.
+    // K7: one lane per block, 64 blocks per wave.  Small alphabets (values fit 16 bits, per-lane arrays fit
+    // LDS: up to ~880 symbols): the E-array fast loop, 0.165 ms on the bench workload against 0.22 ms for the
+    // windowed parser; everything else: the windowed parser (any alphabet / frame size; 0.88 ms on 2300-symbol
+    // alphabets against 1.05 ms for the generic kernel it replaces).  ANSX_PARSE_WIN / ANSX_PARSE_GENERIC
+    // force the other forms (cross-checks in the tests).
     const size_t pf_e = std::max<size_t>(20480, rup(((size_t)max_ns + 2) * 128, 16));
     const size_t pf_lds = pf_e + (size_t)ANSX_PF_SW * 64 * 4 + 21 * 64 * 4;
     u32 stage_words = ANSX_PF_SW;
     if (c->dbg.parse_stage_words >= 2 && c->dbg.parse_stage_words <= ANSX_PF_SW)  // tests: force the in-kernel fallback
         stage_words = c->dbg.parse_stage_words & ~1u;
-    if ((u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024 && !c->dbg.parse_generic) {
+    if (c->dbg.parse_generic) {
+        LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
+            boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+    } else if (!c->dbg.parse_win && (u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
             NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, stage_words);
+    } else if (max_ns <= 1024) {  // preludes of a few hundred bytes: 128 staged words per lane
+        const size_t lds = (size_t)(128 + 72) * 64 * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_win<RF, 128>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_parse_prelude", (k_parse_prelude_win<RF, 128>), (g.nblocks + 63) / 64, 64, lds, s, cont, g,
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
     } else {
-        LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
-            boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+        const size_t lds = (size_t)(256 + 72) * 64 * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_win<RF, 256>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAUNCH(c, "k_parse_prelude", (k_parse_prelude_win<RF, 256>), (g.nblocks + 63) / 64, 64, lds, s, cont, g,
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
     }
     // K8
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
@@ -896,7 +912,7 @@ int ansx_init(int device, ansx_ctx** out)
         delete c;
         return ANSX_ERR_HIP;
     }
-    static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC",
+    static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN",
         "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
@@ -918,6 +934,7 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     if (!strcmp(name, "ANSX_TEST_TABLE16_FIXUP")) c->dbg.table16_fixup = on;
     else if (!strcmp(name, "ANSX_ENCODE_GTAB16")) c->dbg.encode_gtab16 = on;
     else if (!strcmp(name, "ANSX_PARSE_GENERIC")) c->dbg.parse_generic = on;
+    else if (!strcmp(name, "ANSX_PARSE_WIN")) c->dbg.parse_win = on;
     else if (!strcmp(name, "ANSX_DECODE_TABLE")) c->dbg.decode_table = on;
     else if (!strcmp(name, "ANSX_NO_STREAM_LDS")) c->dbg.no_stream_lds = on;
     else if (!strcmp(name, "ANSX_MODEL_FUSED")) c->dbg.model_fused = on;

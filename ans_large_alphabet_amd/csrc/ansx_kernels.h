@@ -1773,6 +1773,141 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
     if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
 }
 
+// ---- K7, windowed form: any alphabet / frame size.
+// One lane per block again, but no per-symbol LDS array: a node's bounds travel WITH the node (the
+// pending right subtrees sit on an LDS stack as (start | size, low, high) in three lane-major arrays, and
+// the top entry is mirrored in registers, so a pop takes its node from registers and only refreshes the
+// mirror), and the bit stream is read through three consecutive 32-bit words held in registers plus one
+// prefetched word: an item takes its <= 31 + 1 bits from one v_alignbit of two of them, and at most one
+// word boundary is crossed per item.  The words come from an LDS window of SW words per lane, staged
+// from the stream and re-staged FOR EVERY LANE as soon as one lane gets near its end (lanes progress at
+// about the same rate, so a wave re-stages once per ~SW words, not once per lane), so a prelude may be
+// arbitrarily long.  The item body is straight-line code under a per-lane predicate: finished or
+// malformed lanes keep their state frozen.
+template <bool RFOLD, u32 SW>
+__global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+{
+    extern __shared__ u32 pw_lds[];
+    u32(*stage)[64] = (u32(*)[64])pw_lds;                       // [SW][64]
+    u32(*stkA)[64] = (u32(*)[64])(pw_lds + SW * 64);            // [24][64] start | size << 16
+    u32(*stkL)[64] = stkA + 24;                                 // low bound of the pending subtree
+    u32(*stkH)[64] = stkL + 24;                                 // high bound; row 23 of each = dump
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x * 64 + lane;
+    const bool live = b < g.nblocks;
+    parse_hdr H;
+    H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;
+    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    u32 err = H.err;
+    const u32 ns = err ? 0u : H.ns;
+    const u8* bp = H.stream + H.pos;                                  // interpolative words start here
+    const u32 avail_words = err ? 0u : (H.sbytes - H.pos) >> 2;       // whole words inside the block stream
+    const u32 maxbits = avail_words * 32;
+    const u32 u = (1u << H.logM) + ns + 1;                            // universe (ans_util.hpp:60), < 2^31
+    u32* cum = g_cum + (u64)(live ? b : 0) * (NSP + 8);
+    u32 a = 0, n = ns, low = 1, high = u + 1;   // current node: items [a, a + n), values in [low, high]
+    u32 ta = 0, tl = 0, th = 0;                 // register mirror of the stack's top entry
+    u32 sp = 0, bitpos = 0, done = 0;
+    u32 base_w = 0;                             // stream word held in stage[0][lane]
+    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;         // words wi, wi + 1, wi + 2 (wi = bitpos >> 5), prefetched wi + 3
+    bool trigger = true;
+    for (;;) {
+        const bool pending = !err && done < ns;
+        if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
+        if (trigger) {
+            // (re)stage every unfinished lane's next SW words from its current word on
+            if (pending) base_w = bitpos >> 5;
+            wave_lds_sync();
+#pragma unroll 4
+            for (u32 j = 0; j < SW / 2; j++) {
+                const u32 w = base_w + 2 * j;
+                u64 v = 0;
+                if (pending && w + 2 <= avail_words) v = ld_u64_unaligned(bp + 4 * (u64)w);
+                else if (pending && w < avail_words) v = ld_u32_unaligned(bp + 4 * (u64)w);
+                stage[2 * j][lane] = (u32)v;
+                stage[2 * j + 1][lane] = (u32)(v >> 32);
+            }
+            wave_lds_sync();
+            w0 = stage[0][lane], w1 = stage[1][lane], w2 = stage[2][lane], w3 = stage[3][lane];
+            trigger = false;
+        }
+        for (;;) {
+            const bool act = !err && done < ns;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+            // node shape (a function of ns alone)
+            const u32 h = (n + 1) >> 1;
+            const u32 n1 = h - 1, n2 = n - h, pe = a + h;
+            // this item (read_center_mid, interp.hpp:47-63)
+            const u32 U = high - n2 - low - n1 + 1;
+            const u32 win = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31u);  // the next 32 bits
+            const u32 Um1 = U - 1;
+            const u32 bb = 32 - __clz(Um1 | 1u) - (Um1 == 0 ? 1u : 0u);      // hi(U-1)+1; 0 for U == 1
+            const u32 lb = bb ? bb - 1 : 0;                                   // bits of the first read (<= 31)
+            const u32 m = (u32)((1ull << bb) - U);
+            const u32 dh = U - ((1u << lb) & (bb ? ~0u : 0u));
+            u32 val = (win & ((1u << lb) - 1u)) + 1;
+            const bool big = (U != 1) && (val > m);
+            val = big ? (2 * val + ((win >> lb) & 1u)) - m - 1 : val;
+            val += dh;
+            if (val > U) val -= U;
+            if (U == 1) val = 1;
+            const u32 v = low + n1 - 1 + val;
+            const u32 len = (U == 1) ? 0u : lb + (big ? 1u : 0u);
+            const bool bad = (U == 0) || (U > u + 1) || (bitpos + len > maxbits);
+            if (act && bad) err = 1;
+            const bool go = act && !bad;
+            // next node: left child, else right child, else the pending one
+            const bool caseA = n1 != 0, caseB = !caseA && n2 != 0;
+            const bool push = go && caseA && n2 != 0;
+            const bool pop = go && !caseA && !caseB;
+            if (go) cum[pe] = v - 1;  // inc[pe - 1]
+            const u32 srow = push ? sp : 23u;
+            stkA[srow][lane] = pe | (n2 << 16);  // start, size < 2^15 (alphabets <= 16384 slots)
+            stkL[srow][lane] = v + 1;
+            stkH[srow][lane] = high;
+            const u32 na = caseA ? a : (caseB ? pe : (ta & 0xFFFFu));
+            const u32 nn = caseA ? n1 : (caseB ? n2 : (ta >> 16));
+            const u32 nlow = caseA ? low : (caseB ? v + 1 : tl);
+            const u32 nhigh = caseA ? v - 1 : (caseB ? high : th);
+            if (push) {  // (before `high` moves on to the child)
+                ta = pe | (n2 << 16), tl = v + 1, th = high;
+            }
+            if (go) {
+                a = na, n = nn, low = nlow, high = nhigh;
+                done++;
+            }
+            sp = sp + (push ? 1u : 0u) - ((pop && sp) ? 1u : 0u);
+            // after a pop the entry below becomes the top: fetch it for the mirror (used at the NEXT pop
+            // at the earliest)
+            const u32 below = sp ? sp - 1 : 23u;
+            const u32 ra = stkA[below][lane], rl = stkL[below][lane], rh = stkH[below][lane];
+            if (pop) {
+                ta = ra, tl = rl, th = rh;
+            }
+            // bit window: at most one word boundary per item
+            const u32 nbit = go ? bitpos + len : bitpos;
+            if ((nbit >> 5) != (bitpos >> 5)) {
+                w0 = w1, w1 = w2, w2 = w3;
+            }
+            bitpos = nbit;
+            const u32 rel = (nbit >> 5) - base_w;
+            w3 = stage[rel + 3 < SW ? rel + 3 : SW - 1][lane];
+            // near the end of the staged words: every lane re-stages before the next item
+            if (__builtin_amdgcn_ballot_w64(go && done < ns && rel + 5 >= SW) != 0) {
+                trigger = true;
+                break;
+            }
+        }
+        if (!trigger) break;
+    }
+    if (live) {
+        binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
+        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    }
+}
+
 // 8 stream bytes ending at byte offset `end` (exclusive): from the LDS-staged copy (aligned
 // words + v_alignbyte) or straight from global memory (one unaligned 8-byte load)
 // per-quad stream ring of the block decoder: ANSX_RING_CHK steps per refill check, 32 bytes per lane

@@ -598,17 +598,33 @@ def test_prelude_parser_paths(A, ctx):
                 for b in range(parts["header"].nblocks)]
     assert min(preludes) > 300, preludes
     assert parts["header"].max_nsyms + (1 << parts["header"].max_log2_frame) + 3 <= 65535  # fast kernel eligible
-    assert np.array_equal(codec.decode(cont, n), data)             # fast loop
+    assert np.array_equal(codec.decode(cont, n), data)             # fast loop (default for small alphabets)
     try:
-        for words in ("64", "32", "2"):                            # 256 / 128 / 8 staged bytes: fallback lanes
+        for words in ("64", "32", "2"):                            # 256 / 128 / 8 staged bytes: fallback lanes of the fast loop
             ctx.debug_set("ANSX_PARSE_STAGE_WORDS", words)
             assert np.array_equal(codec.decode(cont, n), data), words
         ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
+        ctx.debug_set("ANSX_PARSE_WIN", "1")                       # windowed parser
+        assert np.array_equal(codec.decode(cont, n), data)
+        ctx.debug_set("ANSX_PARSE_WIN", None)
         ctx.debug_set("ANSX_PARSE_GENERIC", "1")                   # generic kernel
         assert np.array_equal(codec.decode(cont, n), data)
     finally:
         ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
+        ctx.debug_set("ANSX_PARSE_WIN", None)
         ctx.debug_set("ANSX_PARSE_GENERIC", None)
+    # preludes longer than one staged window (alphabets of thousands of symbols): the windowed parser
+    # re-stages; cross-checked against the generic kernel
+    wide = ol.gen_inputs("uniform24", n, seed=6)
+    for f in (3, 5):
+        cw = codec_for(A, ctx, ol.FOLD, f, block_ints=16384, ckpt_interval=1024)
+        contw = cw.encode(wide)
+        assert np.array_equal(cw.decode(contw, n), wide), f
+        try:
+            ctx.debug_set("ANSX_PARSE_GENERIC", "1")
+            assert np.array_equal(cw.decode(contw, n), wide), f
+        finally:
+            ctx.debug_set("ANSX_PARSE_GENERIC", None)
 
 
 @pytest.mark.parametrize("f", [1, 3])

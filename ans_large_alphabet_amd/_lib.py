@@ -10,7 +10,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libansx.so")
 
-FOLD, RFOLD, MSB = 0, 1, 2
+FOLD, RFOLD, MSB, INT = 0, 1, 2, 3
+FLAG_COMPACT_ALPHABET = 1
 OK, ERR_ARG, ERR_CAPACITY, ERR_FORMAT, ERR_HIP, ERR_NO_DEVICE, ERR_DOMAIN, ERR_MODEL = range(8)
 SINGLE_STREAM = 0xFFFFFFFF
 NO_CHECKPOINTS = 0xFFFFFFFF

@@ -13,8 +13,8 @@ import numpy as np
 from . import _lib as L
 
 
-def make_opts(block_ints=0, ckpt_interval=0):
-    return L.Opts(block_ints, ckpt_interval, 0, 0)
+def make_opts(block_ints=0, ckpt_interval=0, flags=0):
+    return L.Opts(block_ints, ckpt_interval, flags, 0)
 
 
 class Context:
@@ -85,10 +85,11 @@ class _Codec:
     KIND = L.FOLD
     PREFIX = "ANSfold"
 
-    def __init__(self, fidelity, ctx=None, block_ints=0, ckpt_interval=0):
+    def __init__(self, fidelity, ctx=None, block_ints=0, ckpt_interval=0, compact=False):
+        """compact=True: per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130, ANSX_FLAG_COMPACT_ALPHABET)."""
         self.f = int(fidelity)
         self.ctx = ctx
-        self.opts = make_opts(block_ints, ckpt_interval)
+        self.opts = make_opts(block_ints, ckpt_interval, L.FLAG_COMPACT_ALPHABET if compact else 0)
 
     def _ctx(self):
         if self.ctx is None:
@@ -159,8 +160,17 @@ class ANSmsb(_Codec):
     KIND = L.MSB
     PREFIX = "ANSmsb"
 
+    def __init__(self, ctx=None, block_ints=0, ckpt_interval=0, compact=False):
+        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval, compact=compact)
+
+
+class ANSint(_Codec):
+    """methods.hpp:484-497 (include/ans_int.hpp), name() == "ANS": always with per-block alphabet compaction."""
+    KIND = L.INT
+    PREFIX = "ANS"
+
     def __init__(self, ctx=None, block_ints=0, ckpt_interval=0):
-        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval)
+        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval, compact=True)
 
 
 # ---------------------------------------------------------------- container parsing (host)

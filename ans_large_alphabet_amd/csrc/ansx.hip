@@ -17,6 +17,7 @@
 #include "ansx_rfold.h"
 #include "ansx_model.h"
 #include "ansx_gen.h"
+#include "ansx_pa.h"
 
 namespace {
 
@@ -45,7 +46,7 @@ struct ansx_ctx {
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut;
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
@@ -129,10 +130,13 @@ void prof_end(ansx_ctx* c, hipStream_t s)
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // worst-case bytes of one block's reference stream
-size_t block_bound(int kind, u32 f, size_t nb)
+size_t codec_nsp(int kind, u32 f) { return kind == ANSX_MSB ? 2048u : (kind == ANSX_INT ? 16384u : fold_NSP(f)); }
+
+size_t block_bound(int kind, u32 f, size_t nb, bool pa = false)
 {
     size_t hdr = kind == ANSX_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
-    size_t nsp = kind == ANSX_MSB ? 2048u : fold_NSP(f);
+    size_t nsp = codec_nsp(kind, f);
+    if (pa) hdr += 8 + 4 * nb + 8;  // alphabet header: at most 32 bits per distinct value
     return hdr + 8 + 4 * nsp + 7 * nb + 32;
 }
 
@@ -145,14 +149,27 @@ struct Plan {
 
 int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
 {
-    if (kind != ANSX_FOLD && kind != ANSX_RFOLD && kind != ANSX_MSB) return ANSX_ERR_ARG;
-    if (kind == ANSX_MSB) {
-        if (f != 0) return ANSX_ERR_ARG;  // ANSmsb has no fidelity parameter (methods.hpp:499-515)
+    if (kind != ANSX_FOLD && kind != ANSX_RFOLD && kind != ANSX_MSB && kind != ANSX_INT) return ANSX_ERR_ARG;
+    if (kind == ANSX_MSB || kind == ANSX_INT) {
+        if (f != 0) return ANSX_ERR_ARG;  // ANSmsb / ANSint have no fidelity parameter (methods.hpp:484-515)
     } else if (f < 1 || f > ANSX_MAX_FIDELITY) return ANSX_ERR_ARG;  // see include/ansx.h
     if (n == 0) return ANSX_ERR_ARG;
     u32 bi = opts ? opts->block_ints : 0;
     u32 ck = opts ? opts->ckpt_interval : 0;
-    if (opts && opts->flags) return ANSX_ERR_ARG;
+    const u32 flags = opts ? opts->flags : 0;
+    if (flags & ~(u32)ANSX_FLAG_COMPACT_ALPHABET) return ANSX_ERR_ARG;
+    const bool pa = (flags & ANSX_FLAG_COMPACT_ALPHABET) != 0;
+    // ANSint models every value up to the largest (ans_int.hpp:40-48): only meaningful per block on the
+    // dense ranks of the compaction layer; ANSrfold brings its own remap
+    if (kind == ANSX_INT && !pa) return ANSX_ERR_ARG;
+    if (kind == ANSX_RFOLD && pa) return ANSX_ERR_ARG;
+    if (pa) {
+        if (bi == ANSX_SINGLE_STREAM) return ANSX_ERR_ARG;
+        // ranks are 1-based (pseudo_adaptive.cpp:91-103): ANSint's alphabet is sigma + 1 <= 16384 symbols
+        const u32 lim = kind == ANSX_INT ? 16380u : ANSX_PA_MAX_BLOCK;
+        if (bi == 0) bi = kind == ANSX_INT ? 8192u : ANSX_DEFAULT_BLOCK_INTS;
+        if (bi > lim) return ANSX_ERR_ARG;
+    }
     P->plain = (bi == ANSX_SINGLE_STREAM);
     if (bi == 0) bi = ANSX_DEFAULT_BLOCK_INTS;
     if (ck == 0) ck = ANSX_DEFAULT_CKPT_INTERVAL;
@@ -177,10 +194,11 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     g.nckf = geo_nseg(bi, ck) - 1;
     g.f = (u32)f;
     g.kind = (u32)kind;
-    g.map = kind == ANSX_MSB ? map_msb() : map_fold((u32)f);
+    g.pa = pa ? 1u : 0u;
+    g.map = kind == ANSX_MSB ? map_msb() : (kind == ANSX_INT ? map_int() : map_fold((u32)f));
     P->g = g;
     // symbol-array stride: the reference's MAX_SIGMA (ans_fold.hpp:70; ans_msb.hpp:28 has 1280)
-    P->NSP = kind == ANSX_MSB ? 2048u : fold_NSP((u32)f);
+    P->NSP = (u32)codec_nsp(kind, (u32)f);
     Layout L;
     L.index_off = sizeof(ansx_container_header);
     L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
@@ -263,7 +281,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     const bool optimistic = ns_cap != 0;
     const ansx_geo& g = P.g;
     const u32 NB = g.nblocks, NSP = P.NSP, f = g.f;
-    const size_t scr_stride = rup(block_bound(g.kind, f, g.block_ints) + 16, 256);
+    const size_t scr_stride = rup(block_bound(g.kind, f, g.block_ints, g.pa != 0) + 16, 256);
     if (!P.plain && cap < P.lay.payload_off) return ANSX_ERR_CAPACITY;
     int rc;
     if ((rc = ensure(c, c->hist, (size_t)NB * NSP * 4))) return rc;
@@ -305,6 +323,21 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         mostfreq = (const u32*)c->mostfreq.p;
     }
 
+    if (g.pa) {
+        // per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130): alphabet header into the block's
+        // scratch slot, the codec then runs on the 1-based ranks
+        if ((rc = ensure(c, c->mapped, (size_t)NB * g.block_ints * 4))) return rc;
+        if ((rc = ensure(c, c->pa_alpha, (size_t)NB * g.block_ints * 4))) return rc;
+        const size_t lds1 = ((size_t)ANSX_PA_SLOTS + ANSX_PA_MAX_BLOCK) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, (u32*)c->mapped.p, (u32*)c->pa_alpha.p, blk, gflags,
+            1u << 30);
+        const size_t lds2 = ((size_t)2 * ANSX_PA_MAX_BLOCK + 16) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_header, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        LAUNCH(c, "k_pa_header", k_pa_header, NB, 256, lds2, s, g, (const u32*)c->pa_alpha.p, blk, (u8*)c->scratch.p,
+            (u64)scr_stride);
+        src = (const u32*)c->mapped.p;
+    }
     // K1
     u32 chunk = g.block_ints < 16384u ? g.block_ints : 16384u;
     if (chunk & 3u) chunk = (chunk + 3u) & ~3u;
@@ -569,26 +602,26 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 {
     // The first call of a geometry discovers its alphabet size with a mid-call read-back; later calls
     // are launched back to back on that hint and repeat (rarely) if the input outgrew it.
-    const u64 key = ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
+    const u64 key = ((u64)P.g.pa << 48) | ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
     u32 seen = 0;
     int rc = ANSX_RETRY_GENERAL;
     const auto it = c->ns_hint.find(key);
     const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
     const bool eligible = !P.plain && hint != 0 && P.NSP <= 4096 && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
-        && !c->dbg.model_sync;
+        && !c->dbg.model_sync;  // (with compaction too: the hint then describes the alphabets of the rank-remapped blocks)
     if (eligible) {
         u32 ns_cap = (hint + 7u) & ~7u;
         if (ns_cap < 64) ns_cap = 64;
         if (ns_cap > P.NSP) ns_cap = P.NSP;
         // (k_model_fused: the LDS-resident single-kernel model, measured slower than the five tailored
         // kernels -- DESIGN.md section 6 -- and therefore opt-in)
-        if (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK)
+        if (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK && !P.g.pa)
             rc = encode_fast(c, P, d_in, d_out, cap, out_bytes, s, ns_cap, &seen);
         else
             rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, ns_cap);
     }
     bool missed = false;
-    u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK ? 2u : 1u);
+    u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK && !P.g.pa ? 2u : 1u);
     if (rc == ANSX_RETRY_GENERAL) {
         missed = eligible;
         path = eligible ? path | 16u : 0u;
@@ -612,7 +645,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s)
+    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info)
 {
     const u32 T = fold_T(g.f);
     int rc;
@@ -630,24 +663,24 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         stage_words = c->dbg.parse_stage_words & ~1u;
     if (c->dbg.parse_generic) {
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
-            boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+            boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
     } else if (!c->dbg.parse_win && (u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
-            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, stage_words);
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, stage_words, pa_info);
     } else if (max_ns <= 1024) {  // preludes of a few hundred bytes: 128 staged words per lane
         const size_t lds = (size_t)(128 + 72) * 64 * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_win<RF, 128>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_win<RF, 128>), (g.nblocks + 63) / 64, 64, lds, s, cont, g,
-            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
     } else {
         const size_t lds = (size_t)(256 + 72) * 64 * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_win<RF, 256>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_win<RF, 256>), (g.nblocks + 63) / 64, 64, lds, s, cont, g,
-            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags);
+            NSP, boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
     }
     // K8
     const u32 nseg = geo_nseg(g.block_ints, g.ckpt);
@@ -749,7 +782,10 @@ __global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 p
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= g.nblocks) return;
     u64 a = boff[i], b = boff[i + 1];
-    bool bad = (b < a) || (b - a) < 38 || (b - a) >= (1ull << 31) || b > payload_bytes;
+    // a reference stream has at least 2 prelude bytes + one interpolative word + 32 state bytes; with
+    // compaction a one-value block is just its alphabet header (8 bytes + code)
+    const u64 min_bytes = g.pa ? 8 : 38;
+    bool bad = (b < a) || (b - a) < min_bytes || (b - a) >= (1ull << 31) || b > payload_bytes;
     if (i == 0 && a != 0) bad = true;
     if (i == g.nblocks - 1 && b != payload_bytes) bad = true;
     if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
@@ -764,8 +800,9 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     memcpy(&H, h, sizeof(H));
     static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
     if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
-    if (H.kind > 2 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
-    if (H.kind == ANSX_MSB ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > ANSX_MAX_FIDELITY)) return ANSX_ERR_FORMAT;
+    const u32 k = H.kind & 0xFFu;  // bit 8: per-block alphabet compaction
+    if ((H.kind & ~0x1FFu) || k > 3 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
+    if ((k == ANSX_MSB || k == ANSX_INT) ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > ANSX_MAX_FIDELITY)) return ANSX_ERR_FORMAT;
     *out = H;
     return ANSX_OK;
 }
@@ -838,24 +875,25 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         HIPCHK(c, hipStreamSynchronize(s));
         ansx_container_header H;
         if ((rc = parse_header(hp, in_bytes, &H))) return rc;
-        if (H.kind != P.g.kind || H.fidelity != f || H.n != P.g.n) return ANSX_ERR_FORMAT;
+        if ((H.kind & 0xFFu) != P.g.kind || H.fidelity != f || H.n != P.g.n) return ANSX_ERR_FORMAT;
         // the container, not the caller's options, defines the geometry
         ansx_opts o;
         o.block_ints = H.block_ints;
         o.ckpt_interval = H.ckpt_interval ? H.ckpt_interval : ANSX_NO_CHECKPOINTS;
-        o.flags = 0;
+        o.flags = (H.kind & 0x100u) ? ANSX_FLAG_COMPACT_ALPHABET : 0;
         o.reserved = 0;
         if (H.block_ints == ANSX_SINGLE_STREAM) return ANSX_ERR_FORMAT;
-        if ((rc = make_plan((int)H.kind, (int)f, (size_t)H.n, &o, &P))) return ANSX_ERR_FORMAT;
+        if ((rc = make_plan((int)(H.kind & 0xFFu), (int)f, (size_t)H.n, &o, &P))) return ANSX_ERR_FORMAT;
         if (P.g.nblocks != H.nblocks || P.g.nckf != H.ckpts_per_block || P.g.ckpt != H.ckpt_interval
             || P.lay.payload_off != H.payload_offset)
             return ANSX_ERR_FORMAT;
         // (written so that a crafted payload_bytes near 2^64 cannot wrap the sum; payload_offset covers
         // the index and the restart-point area, so this also places those inside the input)
         if (H.payload_offset > in_bytes || H.payload_bytes > in_bytes - H.payload_offset) return ANSX_ERR_FORMAT;
-        if (H.max_log2_frame > 31 || H.max_nsyms == 0 || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
+        // (with compaction a list whose blocks all hold a single distinct value has no model at all)
+        if (H.max_log2_frame > 31 || (H.max_nsyms == 0 && !P.g.pa) || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
         maxM = 1u << H.max_log2_frame;
-        max_ns = H.max_nsyms;
+        max_ns = H.max_nsyms ? H.max_nsyms : 1u;
         cont = d_in;
         boff = (const u64*)(d_in + P.lay.index_off);
         ck_state = (const u64*)(d_in + P.lay.ckstate_off);
@@ -870,13 +908,23 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
         max_block_bytes = c->h_pin[ANSX_G_PAD];
     }
+    const uint4* pa_info = nullptr;
+    if (P.g.pa) {  // alphabet headers first: they tell where every block's codec stream starts
+        if ((rc = ensure(c, c->pa_alpha, (size_t)P.g.nblocks * P.g.block_ints * 4))) return rc;
+        if ((rc = ensure(c, c->pa_info, (size_t)P.g.nblocks * 16))) return rc;
+        LAUNCH(c, "k_pa_parse", k_pa_parse, (P.g.nblocks + 63) / 64, 64, 0, s, cont, P.g, boff, payload_off,
+            (u32*)c->pa_alpha.p, (uint4*)c->pa_info.p, gflags);
+        pa_info = (const uint4*)c->pa_info.p;
+    }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info);
     if (rc) return rc;
+    if (P.g.pa)
+        LAUNCH(c, "k_pa_unmap", k_pa_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, pa_info, d_out, gflags);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return flags_to_status(c->h_pin[ANSX_G_ERR]);
@@ -954,7 +1002,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {
@@ -986,6 +1034,7 @@ int ansx_last_hip_error(const ansx_ctx* c) { return c ? c->last_hip : 0; }
 int ansx_codec_name(int kind, int f, char* buf, size_t buflen)
 {
     if (kind == ANSX_MSB) return snprintf(buf, buflen, "ANSmsb");
+    if (kind == ANSX_INT) return snprintf(buf, buflen, "ANS");  // methods.hpp:485
     return snprintf(buf, buflen, "%s-%d", kind == ANSX_RFOLD ? "ANSrfold" : "ANSfold", f);
 }
 
@@ -993,8 +1042,8 @@ size_t ansx_bound(int kind, int f, size_t n, const ansx_opts* opts)
 {
     Plan P;
     if (make_plan(kind, f, n, opts, &P)) return 0;
-    size_t per = block_bound(kind, (u32)f, 0);
-    return (size_t)P.lay.payload_off + (size_t)P.g.nblocks * per + 7 * n + 64;
+    size_t per = block_bound(kind, (u32)f, 0, false);
+    return (size_t)P.lay.payload_off + (size_t)P.g.nblocks * per + (P.g.pa ? 11 : 7) * n + 64;
 }
 
 int ansx_encode_dev(ansx_ctx* c, int kind, int f, const uint32_t* d_in, size_t n, uint8_t* d_out,
@@ -1217,7 +1266,7 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
     if (!c) return 0;
     const DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info };
     size_t t = 0;
     for (const DevBuf* b : bufs) t += b->cap;
     return t;

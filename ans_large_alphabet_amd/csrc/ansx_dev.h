@@ -42,6 +42,12 @@ ANSX_HD ansx_map map_fold(u32 f)
     ansx_map m = { T, T << 8, T << 16, T, T + D, T + 2 * D, D };
     return m;
 }
+// ANSint (ans_int.hpp:40-48): the symbol is the value, nothing is stripped
+ANSX_HD ansx_map map_int()
+{
+    ansx_map m = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u };
+    return m;
+}
 ANSX_HD ansx_map map_msb()
 {
     ansx_map m = { 257u, 65537u, (1u << 24) + 1u, 257u, 513u, 769u, 256u };
@@ -237,7 +243,8 @@ struct ansx_geo {
     u32 ckpt;        // restart interval in ints (0 = none)
     u32 nckf;        // restart points stored per block (stride)
     u32 f;           // fidelity (0 for ANSmsb)
-    u32 kind;        // 0 fold, 1 rfold, 2 msb
+    u32 kind;        // 0 fold, 1 rfold, 2 msb, 3 int
+    u32 pa;          // 1: per-block alphabet compaction (ansx_pa.h)
     ansx_map map;    // value <-> symbol map of this codec
 };
 

@@ -34,6 +34,10 @@ struct ansx_blk {
     u32 stream_bytes;   // total bytes of this block's reference stream
     u32 hdr_bytes;      // rfold header bytes (4 or 4+4T), 0 for fold
     u32 flag;           // rfold reorder flag
+    // per-block alphabet compaction (ansx_pa.h, src/pseudo_adaptive.cpp:85-130)
+    u32 pre_bytes;      // bytes of the alphabet header in front of the codec stream (0 without compaction)
+    u32 pa_sigma;       // distinct values of the block (0 without compaction; 1: the block has no codec stream)
+    u32 pad_[2];
 };
 
 // encoder table entry (ans_fold.hpp:30-34 enc_entry_fold, plus the reciprocal used for the
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             B->H = H;
             B->thr = H * approx;
         }
-        B->resolved = 0;
+        B->resolved = B->pa_sigma == 1 ? 1u : 0u;  // (compaction: a one-value block has no model)
         B->prev = -1;
         B->status = 0;
     }
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     const u32 ok = (Md == 0.0) ? 1u : 0u;
     meta[0] = ok;
     meta[1] = maxS;
-    if (!ok || maxS >= ANSX_U16_LIMIT) return;  // failed, or the u16 exit: XH is not consulted
+    if (!ok || (maxS >= ANSX_U16_LIMIT && g.kind != 3)) return;  // failed, or the u16 exit: XH is not consulted
     // cross entropy in index order (util.hpp:284-298); note the int accumulators there.
     // Branch-free: an absent symbol contributes p = 0, q = 1 -> +0.0, which leaves the running
     // sum unchanged (the sum is never -0.0), so the 8 log2 evaluations of a chunk overlap and
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         const u32 m2 = __shfl(mt.z, (int)t), m3 = __shfl(mt.w, (int)t);
         if (!m0) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
         const u32 T = batch * ANSX_ATTEMPTS + t;
-        if (m1 >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
+        if (m1 >= ANSX_U16_LIMIT && g.kind != 3) {  // ans_util.hpp:141-145 (ANSint: require_u16 = false, ans_int.hpp:50)
             chosen = prev;
             break;
         }
@@ -650,6 +654,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         }
         return;
     }
+    // ANSint frames above 2^16 (32-bit frequencies, ans_int.hpp:100-110) are not supported by this build's
+    // encoder / decoder tables: refused rather than mis-coded.  (None occurred in 3000 adversarial
+    // low-entropy blocks of up to 16384 ints; the reference caps the other codecs at 2^16 itself.)
+    if (chosen >= 0 && g.kind == 3 && B->m0_log2 + (u32)chosen > 16) chosen = -1;
     if (chosen < 0) {  // "prev" is the all-zero vector: reference's degenerate exit
         if (lane == 0) {
             B->resolved = 1;
@@ -821,12 +829,17 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
 // IPT > 0: at most 256 * IPT symbols, every thread keeps the codes of its <= IPT items from the length
 // pass for the packing pass (one tree descent per item); IPT == 0: any alphabet, two descents.
 // off: [ns] u32, bits: [ns + 1] u32 (LDS; 31 bits per item is the format's ceiling), sh_part: 8 u32.
-template <int IPT>
+// PA == false: the codec prelude (rfold header, vbyte(max_sym), log2 M, code over universe 2^logM + ns + 1),
+//               written behind the block's B->pre_bytes.
+// PA == true:  the alphabet header of per-block compaction (pseudo_adaptive.cpp:106-113): u32 ns, u32 `uni`,
+//               code of the ns running sums over universe `uni`; sets B->pre_bytes.
+template <int IPT, bool PA = false>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
-    u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid)
+    u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
+    u64 uni = 0)
 {
     constexpr bool SMALL = IPT > 0;
-    const u64 u = ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
+    const u64 u = PA ? uni : ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
     if (SMALL) {
 #pragma unroll
@@ -875,19 +888,30 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i));
     }
     __syncthreads();
-    u32 p = 0;
+    const u32 nbytes = nwords * 4;
+    if (PA) {
+        if (tid == 0) {
+            st_u32_unaligned(out, ns);
+            st_u32_unaligned(out + 4, (u32)uni);
+            B->pre_bytes = 8 + nbytes;
+        }
+        for (u32 j = tid; j < nbytes; j += 256) out[8 + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
+        return;
+    }
+    const u32 p0 = B->pre_bytes;
+    u32 p = p0;
     if (g.kind == 1) {  // ans_reorder_fold.hpp:132-154
         const u32 T = fold_T(g.f);
         const u32 flag = B->flag;
-        if (tid == 0) st_u32_unaligned(out, flag);
-        p = 4;
+        if (tid == 0) st_u32_unaligned(out + p, flag);
+        p += 4;
         if (flag) {
             const u32* mf = mostfreq + (u64)b * T;
-            for (u32 i = tid; i < T; i += 256) st_u32_unaligned(out + 4 + 4 * (u64)i, mf[i]);
+            for (u32 i = tid; i < T; i += 256) st_u32_unaligned(out + p + 4 * (u64)i, mf[i]);
             p += 4 * T;
         }
     }
-    const u32 hdr = p;
+    const u32 hdr = p - p0;
     // vbyte(max_sym) (vbyte.hpp:57-80) + log2(M) byte (ans_util.hpp:51)
     u32 ms = ns - 1;
     u32 vb = 1;
@@ -903,7 +927,6 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         out[q] = (u8)logM;
     }
     p += vb + 1;
-    const u32 nbytes = nwords * 4;
     for (u32 j = tid; j < nbytes; j += 256) out[p + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
     if (tid == 0) {
         B->hdr_bytes = hdr;
@@ -925,9 +948,9 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const u32 tid = threadIdx.x;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
-    if (B->status || !B->resolved) {  // (unresolved: optimistic single-batch call, the host repeats it)
+    if (B->status || !B->resolved || B->pa_sigma == 1) {  // (unresolved: optimistic single-batch call, the host repeats it)
         if (tid == 0) {
-            B->prelude_bytes = 0;
+            B->prelude_bytes = B->pa_sigma == 1 ? B->pre_bytes : 0;  // a one-value block is its alphabet header
         }
         return;
     }
@@ -1266,8 +1289,8 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     }
     if (b >= g.nblocks) return;
     ansx_blk* B = &blk[b];
-    if (B->status || !B->resolved) {
-        if (ql == 0) B->stream_bytes = 0;
+    if (B->status || !B->resolved || B->pa_sigma == 1) {
+        if (ql == 0) B->stream_bytes = B->pa_sigma == 1 && !B->status ? B->pre_bytes : 0;
         return;
     }
     const u32 nb = geo_block_n(g, b);
@@ -1497,7 +1520,7 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
     const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
     for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
     u32* w = (u32*)(out + 8);
-    w[0] = g.kind;
+    w[0] = g.kind | (g.pa ? 0x100u : 0u);  // bit 8: per-block alphabet compaction
     w[1] = g.f;
     *(u64*)(out + 16) = g.n;
     w = (u32*)(out + 24);
@@ -1535,9 +1558,13 @@ struct parse_hdr {
     u32 err, ns, logM, flag, pos, sbytes;
     const u8* stream;
 };
+// pa_info (per-block alphabet compaction, ansx_pa.h): {sigma, header bytes, error}; the codec stream starts
+// behind the alphabet header, and a block with one distinct value (or a bad header) has none: err = 2
+// ("nothing to parse", not a format error of its own).
 template <bool RFOLD>
 __device__ __forceinline__ parse_hdr parse_header(const u8* __restrict__ cont, const ansx_geo& g, u32 NSP,
-    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, u32 b)
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, u32 b,
+    const uint4* __restrict__ pa_info = nullptr)
 {
     const u32 T = fold_T(g.f);
     u32 err = 0, ns = 0, logM = 0, flag = 0;
@@ -1545,6 +1572,15 @@ __device__ __forceinline__ parse_hdr parse_header(const u8* __restrict__ cont, c
     const u8* stream = cont + payload_off + boff;
     const u32 sbytes = (u32)(block_off[b + 1] - boff);
     u32 pos = 0;
+    if (pa_info != nullptr) {
+        const uint4 pi = pa_info[b];
+        pos = pi.y;
+        if (pi.x == 1 || pi.z) {
+            parse_hdr H0;
+            H0.err = 2, H0.ns = 1, H0.logM = 0, H0.flag = 0, H0.pos = pos, H0.sbytes = sbytes, H0.stream = stream;
+            return H0;
+        }
+    }
     if (RFOLD) {  // ans_reorder_fold.hpp:238-254
         flag = ld_u32_unaligned(stream);
         pos = 4 + (flag == 1 ? 4 * T : 0);
@@ -1656,17 +1692,17 @@ __device__ __forceinline__ u32 parse_items_generic(const parse_hdr& H, u32 NSP, 
 template <bool RFOLD>
 __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
 {
     __shared__ uint4 stk[20][64];  // [depth][lane]: conflict-free 16-byte accesses
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x * 64 + lane;
     if (b >= g.nblocks) return;
-    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
     u32 err = H.err;
     if (!err) err = parse_items_generic(H, NSP, b, lane, stk, g_cum);
     binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
-    if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    if (err == 1) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
 }
 
 // Fast item loop for the common shapes (frames + alphabets whose interpolative values fit 16 bits,
@@ -1684,7 +1720,8 @@ __global__ __launch_bounds__(64) void k_parse_prelude(const u8* __restrict__ con
 template <bool RFOLD>
 __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, u32 stage_words)
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, u32 stage_words,
+    const uint4* __restrict__ pa_info)
 {
     extern __shared__ __attribute__((aligned(16))) u8 pf_smem[];
     const u32 lane = threadIdx.x;
@@ -1695,7 +1732,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
     u16* E = (u16*)pf_smem;                                         // [max_ns + 2][64]
     u32* stage = (u32*)(pf_smem + ebytes);                          // [ANSX_PF_SW][64]
     u32* stack = stage + ANSX_PF_SW * 64;                           // [21][64], row 20 = dump
-    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    const parse_hdr H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
     u32 err = H.err, slow = 0;
     if (!err) {
         const u32 ns = H.ns;
@@ -1770,7 +1807,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
         if (slow) err = parse_items_generic(H, NSP, b, lane, (uint4(*)[64])pf_smem, g_cum);
     }
     binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
-    if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    if (err == 1) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
 }
 
 // ---- K7, windowed form: any alphabet / frame size.
@@ -1787,7 +1824,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
 template <bool RFOLD, u32 SW>
 __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags)
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
 {
     extern __shared__ u32 pw_lds[];
     u32(*stage)[64] = (u32(*)[64])pw_lds;                       // [SW][64]
@@ -1799,7 +1836,8 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
     const bool live = b < g.nblocks;
     parse_hdr H;
     H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;
-    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b);
+    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
+    const u32 herr = H.err;  // 2: compaction, no codec stream to parse (not an error of this kernel)
     u32 err = H.err;
     const u32 ns = err ? 0u : H.ns;
     const u8* bp = H.stream + H.pos;                                  // interpolative words start here
@@ -1904,7 +1942,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
     }
     if (live) {
         binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
-        if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+        if (err && herr != 2) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
     }
 }
 

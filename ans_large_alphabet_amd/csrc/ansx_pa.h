@@ -1,0 +1,256 @@
+// Per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130): a block is stored as
+//
+//   u32 sigma | u32 universe | interpolative code of the running sums of its sigma distinct values |
+//   codec stream of the block with every value replaced by its 1-based rank among them
+//
+// which is byte for byte what the reference's pseudo_adaptive harness writes for the block (it only
+// measures sizes and never decodes; the decoder below is this build's own).  A block with a single
+// distinct value has no codec stream (:115).  The running sums are kept in 32 bits there, so the sum of a
+// block's distinct values must stay below 2^32 - 1 (ANSX_ERR_DOMAIN otherwise).
+//
+//   encode: k_pa_remap   distinct values (LDS hash set), sorted, ranks by binary search; running sums
+//           k_pa_header  interpolative code of the running sums (the prelude writer's machinery)
+//           ... then the codec's kernels on the remapped block ...
+//   decode: k_pa_parse   alphabet header -> values, one lane per block
+//           ... the codec's decoder writes ranks ...
+//           k_pa_unmap   rank -> value
+#pragma once
+
+#include "ansx_kernels.h"
+
+#define ANSX_PA_SLOTS 20480u  // hash set capacity: >= 1.25 x 16384 values per block
+#define ANSX_PA_EMPTY 0xFFFFFFFFu
+#define ANSX_PA_MAX_BLOCK 16384u
+
+__device__ __forceinline__ u32 pa_slot(u32 v) { return (u32)(((u64)(v * 2654435761u) * ANSX_PA_SLOTS) >> 32); }
+
+// One workgroup of 1024 threads per block.  LDS: hash set (80 KB) + distinct values (64 KB).
+__global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, ansx_geo g, u32* __restrict__ mapped,
+    u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
+{
+    extern __shared__ u32 pa_lds[];
+    __shared__ u32 sh_cnt, sh_max;
+    __shared__ u64 sh_part64[20];
+    u32* keys = pa_lds;                  // [SLOTS]
+    u32* uq = pa_lds + ANSX_PA_SLOTS;    // [16384] distinct values
+    const u32 tid = threadIdx.x, nt = 1024;
+    const u32 b = blockIdx.x;
+    const u32 nb = geo_block_n(g, b);
+    const u32* src = in + (u64)b * g.block_ints;
+    u32* dst = mapped + (u64)b * g.block_ints;
+    for (u32 i = tid; i < ANSX_PA_SLOTS; i += nt) keys[i] = ANSX_PA_EMPTY;
+    if (tid == 0) {
+        sh_cnt = 0;
+        sh_max = 0;
+    }
+    __syncthreads();
+    // distinct values: first inserter of a value appends it to uq
+    u32 lmax = 0;
+    for (u32 i = tid; i < nb; i += nt) {
+        const u32 v = src[i];
+        lmax = v > lmax ? v : lmax;
+        u32 slot = pa_slot(v);
+        for (u32 probes = 0; probes < ANSX_PA_SLOTS; probes++) {
+            const u32 old = atomicCAS(&keys[slot], ANSX_PA_EMPTY, v);
+            if (old == ANSX_PA_EMPTY) uq[atomicAdd(&sh_cnt, 1u)] = v;
+            if (old == ANSX_PA_EMPTY || old == v) break;
+            slot = slot + 1 == ANSX_PA_SLOTS ? 0 : slot + 1;
+        }
+    }
+    atomicMax(&sh_max, lmax);
+    __syncthreads();
+    const u32 sigma = sh_cnt;
+    if (tid == 0 && sh_max >= value_limit) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
+    // sort the distinct values (bitonic, padded to a power of two)
+    u32 N2 = 2;
+    while (N2 < sigma) N2 <<= 1;
+    for (u32 i = sigma + tid; i < N2; i += nt) uq[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 k = 2; k <= N2; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < N2; i += nt) {
+                const u32 ixj = i ^ j;
+                if (ixj > i) {
+                    const bool asc = (i & k) == 0;
+                    const u32 x = uq[i], y = uq[ixj];
+                    if ((x > y) == asc) {
+                        uq[i] = y;
+                        uq[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // running sums of the alphabet (pseudo_adaptive.cpp:103-105, u32 there: the exact sum must fit)
+    {
+        const u32 per = (sigma + nt - 1) / nt;
+        const u32 lo = tid * per, hi = (lo + per) < sigma ? (lo + per) : sigma;
+        u64 sum = 0;
+        for (u32 j = lo; j < hi; j++) sum += uq[j];
+        u64 total;
+        u64 run = block_excl_scan<u64>(sum, sh_part64, tid, nt, &total);
+        u32* as = alpha_sum + (u64)b * g.block_ints;
+        for (u32 j = lo; j < hi; j++) {
+            run += uq[j];
+            as[j] = (u32)run;
+        }
+        if (tid == 0) {
+            if (total >= 0xFFFFFFFFull) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
+            blk[b].pa_sigma = sigma;
+        }
+    }
+    // 1-based rank of every value (:91-103)
+    for (u32 i = tid; i < nb; i += nt) {
+        const u32 v = src[i];
+        u32 lo = 0, hi = sigma;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (uq[mid] < v) lo = mid + 1;
+            else hi = mid;
+        }
+        dst[i] = lo + 1;
+    }
+}
+
+// Alphabet header: one workgroup of 256 threads per block (the prelude writer's generic path).
+__global__ __launch_bounds__(256) void k_pa_header(ansx_geo g, const u32* __restrict__ alpha_sum,
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride)
+{
+    extern __shared__ u32 lds32[];
+    __shared__ u32 sh_part[8];
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    ansx_blk* B = &blk[b];
+    const u32 sigma = B->pa_sigma;
+    const u32* as = alpha_sum + (u64)b * g.block_ints;
+    u32* off = lds32;                          // [sigma]
+    u32* bits = lds32 + ANSX_PA_MAX_BLOCK;     // bit buffer
+    const u64 uni = (u64)as[sigma - 1] + 1;    // block_alphabet.back() + 1 (:108)
+    prelude_emit<0, true>(g, B, sigma, 0, as, off, bits, sh_part, scratch + (u64)b * scr_stride, nullptr, b, tid, uni);
+}
+
+// Decoder side: alphabet header -> distinct values, one lane per block (serial bit parsing; values and the
+// universe need up to 33 bits, so the interval arithmetic is 64-bit).  Writes the values (not the running
+// sums) to alpha[b][0..sigma), and pa_info[b] = {sigma, header bytes, error}.
+__global__ __launch_bounds__(64) void k_pa_parse(const u8* __restrict__ cont, ansx_geo g,
+    const u64* __restrict__ block_off, u64 payload_off, u32* __restrict__ alpha, uint4* __restrict__ pa_info,
+    u32* __restrict__ gflags)
+{
+    __shared__ uint4 stkA[24][64];  // pending right subtrees: (a, n) and the bounds as two 64-bit halves
+    __shared__ uint2 stkB[24][64];
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x * 64 + lane;
+    if (b >= g.nblocks) return;
+    const u64 boff = block_off[b];
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const u32 nb = geo_block_n(g, b);
+    u32 err = 0, sigma = 0, hb = 0;
+    u32* out = alpha + (u64)b * g.block_ints;
+    if (sbytes < 8) err = 1;
+    if (!err) {
+        sigma = ld_u32_unaligned(stream);
+        const u64 uni = ld_u32_unaligned(stream + 4);
+        if (sigma == 0 || sigma > nb || sigma > ANSX_PA_MAX_BLOCK) err = 1;
+        const u8* bp = stream + 8;
+        const u64 maxbits = (u64)(sbytes - 8) * 8;
+        u64 bitpos = 0;
+        auto getbits = [&](u32 nbits) -> u32 {  // nbits in [0, 32]; never reads past the block's bytes
+            if (nbits == 0) return 0u;
+            const u64 byte = bitpos >> 3;
+            u64 w = 0;
+            const u64 avail = (u64)(sbytes - 8) - byte;
+            if (avail >= 8) w = ld_u64_unaligned(bp + byte);
+            else
+                for (u64 i = 0; i < avail; i++) w |= (u64)bp[byte + i] << (8 * i);
+            const u32 v = (u32)((w >> (bitpos & 7)) & (nbits >= 32 ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
+            bitpos += nbits;
+            return v;
+        };
+        u32 sp = 0, a = 0, n = sigma;
+        u64 low = 1, high = uni + 1;
+        u64 prev_sum = 0;  // values come out in index order only within a subtree: differences are taken afterwards
+        (void)prev_sum;
+        for (u32 it = 0; it < sigma && !err; it++) {
+            if (n == 0) {
+                if (sp == 0) {
+                    err = 1;
+                    break;
+                }
+                sp--;
+                const uint4 e = stkA[sp][lane];
+                const uint2 e2 = stkB[sp][lane];
+                a = e.x;
+                n = e.y;
+                low = (u64)e.z | ((u64)e.w << 32);
+                high = (u64)e2.x | ((u64)e2.y << 32);
+            }
+            const u32 h = (n + 1) >> 1;
+            const u32 n1 = h - 1, n2 = n - h;
+            const u64 U = high - n2 - low - n1 + 1;
+            if (U == 0 || U > uni + 1 || bitpos > maxbits) {
+                err = 1;
+                break;
+            }
+            u64 val = 1;  // read_center_mid (interp.hpp:47-63)
+            if (U != 1) {
+                const u32 bb = 64 - __clzll((unsigned long long)(U - 1));  // hi(U-1)+1, <= 33
+                const u64 m = (1ull << bb) - U;
+                const u64 dh = U - (1ull << (bb - 1));
+                val = (u64)getbits(bb - 1) + 1;
+                if (val > m) val = (2 * val + getbits(1)) - m - 1;
+                val += dh;
+                if (val > U) val -= U;
+            }
+            const u64 v = low + n1 - 1 + val;
+            out[a + h - 1] = (u32)(v - 1);  // running sum of the alphabet up to this value
+            if (n2) {
+                stkA[sp][lane] = make_uint4(a + h, n2, (u32)(v + 1), (u32)((v + 1) >> 32));
+                stkB[sp][lane] = make_uint2((u32)high, (u32)(high >> 32));
+                sp++;
+            }
+            n = n1;
+            high = v - 1;
+        }
+        if (bitpos > maxbits) err = 1;
+        hb = 8 + 4 * (u32)((bitpos + 31) >> 5);
+        if (hb > sbytes) err = 1;
+        if (!err) {  // running sums -> values (this lane wrote every entry itself)
+            u32 prev = 0;
+            for (u32 j = 0; j < sigma; j++) {
+                const u32 cur = out[j];
+                if (j && cur <= prev) err = 1;  // distinct ascending values: sums strictly increase (value 0 only first)
+                out[j] = cur - prev;
+                prev = cur;
+            }
+        }
+    }
+    pa_info[b] = make_uint4(sigma, hb, err, 0);
+    if (err) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+}
+
+// rank -> value on the decoded block; a one-value block is filled here (it has no codec stream)
+__global__ __launch_bounds__(256) void k_pa_unmap(ansx_geo g, const u32* __restrict__ alpha,
+    const uint4* __restrict__ pa_info, u32* __restrict__ out, u32* __restrict__ gflags)
+{
+    const u32 b = blockIdx.x;
+    const uint4 pi = pa_info[b];
+    if (pi.z) return;
+    const u32 nb = geo_block_n(g, b);
+    const u32* al = alpha + (u64)b * g.block_ints;
+    u32* o = out + (u64)b * g.block_ints;
+    const u32 sigma = pi.x;
+    u32 bad = 0;
+    if (sigma == 1) {
+        const u32 v = al[0];
+        for (u32 i = threadIdx.x; i < nb; i += 256) o[i] = v;
+        return;
+    }
+    for (u32 i = threadIdx.x; i < nb; i += 256) {
+        const u32 r = o[i];
+        if (r < 1 || r > sigma) bad = 1;
+        else o[i] = al[r - 1];
+    }
+    if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+}

@@ -59,10 +59,11 @@ struct Runtime {
     }
 };
 
-template <int KIND, uint32_t fidelity, uint32_t BLOCK_INTS> struct Codec {
-    static std::string name()  // methods.hpp:530-533 / 550-553 / 500
+template <int KIND, uint32_t fidelity, uint32_t BLOCK_INTS, uint32_t FLAGS = 0u> struct Codec {
+    static std::string name()  // methods.hpp:530-533 / 550-553 / 500 / 485
     {
         if (KIND == ANSX_MSB) return "ANSmsb";
+        if (KIND == ANSX_INT) return "ANS";
         return std::string(KIND == ANSX_RFOLD ? "ANSrfold-" : "ANSfold-") + std::to_string(fidelity);
     }
     static ansx_opts opts()
@@ -70,7 +71,7 @@ template <int KIND, uint32_t fidelity, uint32_t BLOCK_INTS> struct Codec {
         ansx_opts o;
         o.block_ints = BLOCK_INTS;
         o.ckpt_interval = 0;
-        o.flags = 0;
+        o.flags = FLAGS;
         o.reserved = 0;
         return o;
     }
@@ -107,6 +108,12 @@ template <uint32_t fidelity> using ANSrfoldGPU = ansx::Codec<ANSX_RFOLD, fidelit
 // ANSmsb (methods.hpp:499-515): the fixed-threshold MSB fold, same kernels, no fidelity
 using ANSmsbGPU = ansx::Codec<ANSX_MSB, 0u, 0u>;
 using ANSmsbGPUStream = ansx::Codec<ANSX_MSB, 0u, ANSX_SINGLE_STREAM>;
+// ANSint (methods.hpp:484-497): 32-bit frequencies over the values themselves -- on the GPU through the
+// per-block alphabet compaction of src/pseudo_adaptive.cpp:85-130 (every block = alphabet header + ANSint
+// stream of the block's 1-based ranks, as that harness writes it), which is also available for the others
+using ANSintGPU = ansx::Codec<ANSX_INT, 0u, 0u, ANSX_FLAG_COMPACT_ALPHABET>;
+using ANSmsbGPUCompact = ansx::Codec<ANSX_MSB, 0u, 0u, ANSX_FLAG_COMPACT_ALPHABET>;
+template <uint32_t fidelity> using ANSfoldGPUCompact = ansx::Codec<ANSX_FOLD, fidelity, 0u, ANSX_FLAG_COMPACT_ALPHABET>;
 // exactly one reference stream, byte-identical to ANSfold<f>::encode / ANSrfold<f>::encode
 template <uint32_t fidelity> using ANSfoldGPUStream = ansx::Codec<ANSX_FOLD, fidelity, ANSX_SINGLE_STREAM>;
 template <uint32_t fidelity> using ANSrfoldGPUStream = ansx::Codec<ANSX_RFOLD, fidelity, ANSX_SINGLE_STREAM>;

@@ -53,7 +53,10 @@ typedef struct ansx_ctx ansx_ctx;
 typedef enum {
     ANSX_FOLD = 0,  /* ANSfold<f>  */
     ANSX_RFOLD = 1, /* ANSrfold<f> */
-    ANSX_MSB = 2    /* ANSmsb (include/methods.hpp:499-515 -> include/ans_msb.hpp); fidelity must be 0 */
+    ANSX_MSB = 2,   /* ANSmsb (include/methods.hpp:499-515 -> include/ans_msb.hpp); fidelity must be 0 */
+    ANSX_INT = 3    /* ANSint, name() == "ANS" (include/methods.hpp:484-497 -> include/ans_int.hpp); fidelity must be 0;
+                       only with ANSX_FLAG_COMPACT_ALPHABET (its model spans every value up to the largest, which
+                       is only workable per block on dense ranks); frames are limited to 2^16 (ANSX_ERR_MODEL) */
 } ansx_kind;
 
 typedef enum {
@@ -77,17 +80,26 @@ typedef enum {
 #define ANSX_DEFAULT_BLOCK_INTS 16384u
 #define ANSX_DEFAULT_CKPT_INTERVAL 1024u
 
+/* opts.flags.  ANSX_FLAG_COMPACT_ALPHABET: per-block alphabet compaction, the scheme of the reference's
+ * src/pseudo_adaptive.cpp:85-130 -- every block is stored as u32 sigma | u32 universe | interpolative code of
+ * the running sums of its sigma distinct values | the codec's stream of the block with each value replaced
+ * by its 1-based rank among them (nothing when sigma == 1): byte for byte what that harness writes for the
+ * block (it only measures sizes; decoding is this library's own).  For ANSX_FOLD, ANSX_MSB, ANSX_INT; blocks
+ * of at most 16384 ints (ANSX_INT: 16380, default 8192); the sum of a block's distinct values must stay
+ * below 2^32 - 1, as in the harness (ANSX_ERR_DOMAIN). */
+#define ANSX_FLAG_COMPACT_ALPHABET 1u
+
 typedef struct {
     uint32_t block_ints;    /* ints per independent reference stream; 0 = default             */
     uint32_t ckpt_interval; /* ints between decoder restart points (multiple of 4); 0 = default */
-    uint32_t flags;         /* reserved, must be 0                                             */
+    uint32_t flags;         /* ANSX_FLAG_* bits                                                */
     uint32_t reserved;
 } ansx_opts;
 
 /* 64-byte container header (little endian), see DESIGN.md section 3. */
 typedef struct {
     uint8_t magic[8];       /* "ANSXv1\0\0"                                                    */
-    uint32_t kind;
+    uint32_t kind;          /* ansx_kind | 0x100 if ANSX_FLAG_COMPACT_ALPHABET                  */
     uint32_t fidelity;
     uint64_t n;             /* total ints                                                       */
     uint32_t block_ints;

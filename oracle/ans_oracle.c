@@ -17,6 +17,7 @@
 
 /* kind 2 = ANSmsb (include/ans_msb.hpp): same skeleton, different byte-stripping map */
 #define ANS_ORACLE_MSB 2
+#define ANS_ORACLE_INT 3
 #define MSB_MAX_SIGMA 1280u /* ans_msb.hpp:28 */
 
 static inline uint32_t fold_T(uint32_t f) { return 1u << (f + 7); }          /* ans_fold.hpp:43 */
@@ -133,9 +134,10 @@ static double cross_entropy_u64_u32(const uint64_t* P, size_t np, const uint32_t
     return -H0;
 }
 
-/* include/ans_util.hpp:100-157 with require_u16 = true, H_approx = 1 */
-uint64_t ans_oracle_adjust_freqs(const uint64_t* freqs, size_t nfreqs, uint32_t largest_sym,
-    uint32_t* scaled)
+/* include/ans_util.hpp:100-157, H_approx = 1; require_u16 as passed (true for the fold codecs and ANSmsb,
+ * false for ANSint, ans_int.hpp:50) */
+uint64_t ans_oracle_adjust_freqs_ex(const uint64_t* freqs, size_t nfreqs, uint32_t largest_sym,
+    uint32_t* scaled, int require_u16)
 {
     size_t sigma = 0;
     uint64_t freq_sum = 0;
@@ -180,7 +182,7 @@ uint64_t ans_oracle_adjust_freqs(const uint64_t* freqs, size_t nfreqs, uint32_t 
         for (size_t i = 0; i < ns; i++)
             if (scaled[i] > maxf) maxf = scaled[i];
         double XH = cross_entropy_u64_u32(freqs, nfreqs, scaled, ns);
-        if (maxf >= u16_limit) {
+        if (require_u16 && maxf >= u16_limit) {
             memcpy(scaled, prev, ns * sizeof(uint32_t));
             break;
         }
@@ -193,6 +195,12 @@ uint64_t ans_oracle_adjust_freqs(const uint64_t* freqs, size_t nfreqs, uint32_t 
     uint64_t M = 0;
     for (size_t i = 0; i < ns; i++) M += scaled[i];
     return M;
+}
+
+uint64_t ans_oracle_adjust_freqs(const uint64_t* freqs, size_t nfreqs, uint32_t largest_sym,
+    uint32_t* scaled)
+{
+    return ans_oracle_adjust_freqs_ex(freqs, nfreqs, largest_sym, scaled, 1);
 }
 
 /* ---------------------------------------------------------------- bit I/O + interpolative */
@@ -429,6 +437,9 @@ static int cmp_cv(const void* a, const void* b) /* (-count, value) ascending: an
 
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n)
 {
+    /* ANSint: the model spans every value up to the largest; this oracle covers inputs whose largest value
+     * does not exceed n + 1024 (the per-block dense remap of pseudo_adaptive.cpp, small-valued lists) */
+    if (kind == ANS_ORACLE_INT) return 16 + 8 * (n + 1027) + 4 * n + 32 + 64;
     size_t nsyms_max = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (size_t)fold_T(f) + 3u * (size_t)fold_D(f);
     size_t hdr = kind == ANS_ORACLE_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
     return hdr + 8 + 4 * nsyms_max + 8 + 7 * n + 32;
@@ -438,11 +449,17 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     size_t cap, ans_oracle_info* info, size_t ckpt_interval, uint64_t* ckpt_states,
     uint32_t* ckpt_off, size_t* n_ckpt)
 {
-    if (kind == ANS_ORACLE_MSB) f = 1; /* fidelity is not a parameter of ANSmsb */
+    if (kind == ANS_ORACLE_MSB || kind == ANS_ORACLE_INT) f = 1; /* fidelity is not a parameter of ANSmsb / ANSint */
     if (n == 0 || f < 1 || f > 7) return 0; /* n == 0 never terminates in the reference (F4) */
     if (cap < ans_oracle_bound(kind, f, n)) return 0;
-    const uint32_t T = fold_T(f);
-    const uint32_t MAX_SIGMA = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f);
+    uint32_t int_max = 0; /* ANSint (ans_int.hpp:40-48): symbols are the values, alphabet = max value + 1 */
+    if (kind == ANS_ORACLE_INT) {
+        for (size_t i = 0; i < n; i++)
+            if (in[i] > int_max) int_max = in[i];
+        if ((size_t)int_max > n + 1024) return 0; /* outside this oracle's range, see ans_oracle_bound */
+    }
+    const uint32_t T = kind == ANS_ORACLE_INT ? 0xFFFFFFFFu : fold_T(f); /* ANSint never strips bytes */
+    const uint32_t MAX_SIGMA = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (kind == ANS_ORACLE_INT ? int_max + 1 : fold_max_sigma(f));
     ans_oracle_info local;
     memset(&local, 0, sizeof(local));
 
@@ -517,7 +534,7 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     for (size_t i = 0; i < n; i++) {
         uint32_t mv;
         MAP_VALUE(in[i], mv);
-        uint32_t s = kind == ANS_ORACLE_MSB ? msb_map(mv, NULL) : ans_oracle_fold(f, mv, NULL);
+        uint32_t s = kind == ANS_ORACLE_MSB ? msb_map(mv, NULL) : (kind == ANS_ORACLE_INT ? mv : ans_oracle_fold(f, mv, NULL));
         freqs[s]++;
         if (s > max_sym) max_sym = s;
     }
@@ -526,7 +543,7 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     }
     size_t nsyms = (size_t)max_sym + 1;
     uint32_t* nfreqs = (uint32_t*)calloc(nsyms, sizeof(uint32_t));
-    uint64_t M = ans_oracle_adjust_freqs(freqs, MAX_SIGMA, max_sym, nfreqs); /* :79 */
+    uint64_t M = ans_oracle_adjust_freqs_ex(freqs, MAX_SIGMA, max_sym, nfreqs, kind != ANS_ORACLE_INT); /* :79; ans_int.hpp:50 */
     free(freqs);
     if (M == 0 || (M & (M - 1)) != 0) { /* degenerate "prev is all zero" exit */
         free(nfreqs);
@@ -645,8 +662,8 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
 /* ---------------------------------------------------------------- decode */
 
 typedef struct {
-    uint16_t freq;
-    uint16_t offset;
+    uint32_t freq;   /* u16 in the fold codecs; ANSint's LARGE table has 32 bits (ans_int.hpp:100-110) */
+    uint32_t offset;
     uint32_t value;  /* unfolded high part (reference packs this with nbytes, ans_fold.hpp:198-200) */
     uint32_t nbytes;
 } dec_entry;
@@ -654,7 +671,7 @@ typedef struct {
 int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in, uint32_t* out,
     size_t n, int ref_f3_compat)
 {
-    if (kind == ANS_ORACLE_MSB) f = 1;
+    if (kind == ANS_ORACLE_MSB || kind == ANS_ORACLE_INT) f = 1;
     if (f < 1 || f > 7) return -1;
     const uint32_t T = fold_T(f);
     const uint8_t* p = in;
@@ -670,7 +687,9 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     }
     uint32_t max_sym_peek; /* guard against corrupt input: the alphabet has < 2^(f+9) symbols */
     vbyte_get(p, &max_sym_peek);
-    if (max_sym_peek >= (kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f))) return -2;
+    if (kind == ANS_ORACLE_INT ? (size_t)max_sym_peek > n + 1024
+                               : max_sym_peek >= (kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f)))
+        return -2;
     uint32_t* nfreqs = (uint32_t*)calloc((size_t)max_sym_peek + 2, sizeof(uint32_t));
     uint32_t lg = 0;
     size_t nsyms = ans_oracle_read_prelude(p, nfreqs, &lg);
@@ -684,7 +703,12 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     uint64_t base = 0;
     for (size_t s = 0; s < nsyms; s++) {
         uint32_t k;
-        uint32_t val = kind == ANS_ORACLE_MSB ? msb_unmap((uint32_t)s, &k) : ans_oracle_unfold(f, (uint32_t)s, &k);
+        uint32_t val;
+        if (kind == ANS_ORACLE_INT) { /* ans_int.hpp:134-143: entry->sym = sym */
+            val = (uint32_t)s;
+            k = 0;
+        } else
+            val = kind == ANS_ORACLE_MSB ? msb_unmap((uint32_t)s, &k) : ans_oracle_unfold(f, (uint32_t)s, &k);
         if (kind == ANS_ORACLE_RFOLD) {
             /* ans_reorder_fold.hpp:207-219: s < T -> most_frequent[s] + T; final "- T" at :301 */
             if (flag == 1) {
@@ -698,8 +722,8 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
             }
         }
         for (uint32_t k2 = 0; k2 < nfreqs[s]; k2++) {
-            table[base + k2].freq = (uint16_t)nfreqs[s];
-            table[base + k2].offset = (uint16_t)k2;
+            table[base + k2].freq = nfreqs[s];
+            table[base + k2].offset = k2;
             table[base + k2].value = val;
             table[base + k2].nbytes = k;
         }
@@ -756,4 +780,110 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
 #undef DEC_SYM
     free(table);
     return 0;
+}
+
+
+/* ---------------------------------------------------------------- per-block alphabet compaction */
+
+/* One block of src/pseudo_adaptive.cpp run<t_compressor>() (:85-130): u32 alphabet size, u32 universe
+ * (sum of the block's distinct values + 1, u32 arithmetic), interpolative code of the running sums of the
+ * ascending distinct values (:106-113; interp.hpp:99-108), then t_compressor::encode of the block remapped to
+ * 1-based ranks (:91-103,115-123) -- nothing when the block has a single distinct value.  Restart points of
+ * the codec stream are reported relative to the start of the WHOLE block stream. */
+size_t ans_oracle_pa_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uint8_t* out, size_t cap,
+    ans_oracle_pa_info* pinfo, ans_oracle_info* info, size_t ckpt_interval, uint64_t* ckpt_states,
+    uint32_t* ckpt_off, size_t* n_ckpt)
+{
+    if (n == 0 || kind == ANS_ORACLE_RFOLD) return 0;
+    uint32_t* sorted = (uint32_t*)malloc(sizeof(uint32_t) * n);
+    uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * n);
+    memcpy(sorted, in, sizeof(uint32_t) * n);
+    radix_sort_u32(sorted, tmp, n);
+    size_t sigma = 0;
+    for (size_t i = 0; i < n; i++)
+        if (i == 0 || sorted[i] != sorted[i - 1]) tmp[sigma++] = sorted[i]; /* distinct values, ascending */
+    /* remap: rank (1-based) of every value; running sums of the alphabet in u32 */
+    uint32_t* mapped = (uint32_t*)malloc(sizeof(uint32_t) * n);
+    for (size_t i = 0; i < n; i++) {
+        size_t lo = 0, hi = sigma;
+        while (lo < hi) {
+            size_t mid = (lo + hi) >> 1;
+            if (tmp[mid] < in[i]) lo = mid + 1;
+            else hi = mid;
+        }
+        mapped[i] = (uint32_t)lo + 1;
+    }
+    uint64_t exact = 0;
+    for (size_t i = 0; i < sigma; i++) {
+        exact += tmp[i];
+        sorted[i] = (uint32_t)exact; /* block_alphabet[k] += block_alphabet[k - 1], :103-105 */
+    }
+    if (exact >= 0xFFFFFFFFull || cap < 8 + 4 * sigma + 8 + ans_oracle_bound(kind, f, n)) { /* u32 sums must not wrap */
+        free(sorted);
+        free(tmp);
+        free(mapped);
+        return 0;
+    }
+    uint32_t universe = sorted[sigma - 1] + 1;
+    uint32_t sg = (uint32_t)sigma;
+    memcpy(out, &sg, 4);
+    memcpy(out + 4, &universe, 4);
+    bitw w;
+    memset(&w, 0, sizeof(w));
+    w.out = out + 8;
+    encode_interp(&w, sorted, sigma, 1, (uint64_t)universe + 1);
+    size_t hb = 8 + bw_flush(&w);
+    if (pinfo) {
+        pinfo->sigma = sg;
+        pinfo->universe = universe;
+        pinfo->header_bytes = (uint32_t)hb;
+        pinfo->interp_bits = (uint32_t)w.total_bits;
+    }
+    size_t total = hb;
+    if (n_ckpt) *n_ckpt = 0;
+    if (info) memset(info, 0, sizeof(*info));
+    if (sigma != 1) {
+        size_t nck = 0;
+        size_t cb = ans_oracle_encode(kind, f, mapped, n, out + hb, cap - hb, info, ckpt_interval, ckpt_states, ckpt_off, &nck);
+        if (cb == 0) total = 0;
+        else {
+            total += cb;
+            if (ckpt_off)
+                for (size_t i = 0; i < nck; i++) ckpt_off[i] += (uint32_t)hb;
+            if (n_ckpt) *n_ckpt = nck;
+        }
+    }
+    free(sorted);
+    free(tmp);
+    free(mapped);
+    return total;
+}
+
+/* the inverse (this build's own: pseudo_adaptive.cpp never decodes) */
+int ans_oracle_pa_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
+{
+    if (nbytes < 8) return -1;
+    uint32_t sigma, universe;
+    memcpy(&sigma, in, 4);
+    memcpy(&universe, in + 4, 4);
+    if (sigma == 0 || sigma > n) return -2;
+    uint32_t* alpha = (uint32_t*)malloc(sizeof(uint32_t) * sigma);
+    bitr r;
+    r.in = in + 8;
+    r.bitpos = 0;
+    decode_interp(&r, alpha, sigma, 1, (uint64_t)universe + 1);
+    size_t hb = 8 + 4 * (size_t)((r.bitpos + 31) / 32);
+    for (size_t i = sigma; i-- > 1;) alpha[i] -= alpha[i - 1]; /* running sums -> values */
+    int rc = 0;
+    if (sigma == 1) {
+        for (size_t i = 0; i < n; i++) out[i] = alpha[0];
+    } else {
+        rc = ans_oracle_decode(kind, f, in + hb, nbytes - hb, out, n, 0);
+        for (size_t i = 0; rc == 0 && i < n; i++) {
+            if (out[i] < 1 || out[i] > sigma) rc = -4;
+            else out[i] = alpha[out[i] - 1];
+        }
+    }
+    free(alpha);
+    return rc;
 }

@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-enum { ANS_ORACLE_FOLD = 0, ANS_ORACLE_RFOLD = 1, ANS_ORACLE_MSB_KIND = 2 /* ANSmsb, include/ans_msb.hpp; f ignored */ };
+enum { ANS_ORACLE_FOLD = 0, ANS_ORACLE_RFOLD = 1, ANS_ORACLE_MSB_KIND = 2 /* ANSmsb, include/ans_msb.hpp; f ignored */,
+    ANS_ORACLE_INT_KIND = 3 /* ANSint, include/ans_int.hpp (methods.hpp:484-497); f ignored; inputs with max value <= n + 1024 */ };
 
 typedef struct {
     uint32_t max_sym;       /* largest folded symbol in the block                         */
@@ -65,6 +66,24 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
  * 0 decodes correctly.  Returns 0 on success. */
 int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes, uint32_t* out,
     size_t n, int ref_f3_compat);
+
+/* include/ans_util.hpp:100-157 with require_u16 as given (false = ANSint, ans_int.hpp:50). */
+uint64_t ans_oracle_adjust_freqs_ex(const uint64_t* freqs, size_t nfreqs, uint32_t largest_sym,
+    uint32_t* scaled, int require_u16);
+
+/* One block of src/pseudo_adaptive.cpp:85-130 (per-block alphabet compaction): alphabet header + codec
+ * stream of the block remapped to 1-based ranks; kind 0 (ANSfold<f>), 2 (ANSmsb) or 3 (ANSint). */
+typedef struct {
+    uint32_t sigma;        /* distinct values in the block                         */
+    uint32_t universe;     /* sum of the distinct values + 1 (u32)                 */
+    uint32_t header_bytes; /* 8 + interpolative words                              */
+    uint32_t interp_bits;  /* valid bits of the header's interpolative code        */
+} ans_oracle_pa_info;
+size_t ans_oracle_pa_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uint8_t* out, size_t cap,
+    ans_oracle_pa_info* pinfo, ans_oracle_info* info, size_t ckpt_interval, uint64_t* ckpt_states,
+    uint32_t* ckpt_off, size_t* n_ckpt);
+/* Inverse of ans_oracle_pa_encode (the reference harness never decodes: this build's own). */
+int ans_oracle_pa_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n);
 
 /* Worst-case stream size for one encode() call. */
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n);

@@ -28,6 +28,7 @@
 #include "ans_fold.hpp"
 #include "ans_reorder_fold.hpp"
 #include "ans_msb.hpp"
+#include "ans_int.hpp"
 
 namespace {
 
@@ -68,9 +69,10 @@ void rfold_dec(const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
 
 extern "C" {
 
-// kind: 0 = ANSfold<f>, 1 = ANSrfold<f>, 2 = ANSmsb (methods.hpp:499-515)
+// kind: 0 = ANSfold<f>, 1 = ANSrfold<f>, 2 = ANSmsb (methods.hpp:499-515), 3 = ANSint (methods.hpp:484-497)
 size_t ref_encode(int kind, int f, const uint32_t* in, size_t n, uint8_t* out, size_t cap)
 {
+    if (kind == 3) return ans_int_compress(out, cap, in, n);
     if (kind == 2) return ans_msb_compress(out, cap, in, n);
     if (kind == 0) {
         DISPATCH_F(fold_enc, in, n, out, cap)
@@ -82,6 +84,10 @@ size_t ref_encode(int kind, int f, const uint32_t* in, size_t n, uint8_t* out, s
 
 void ref_decode(int kind, int f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n)
 {
+    if (kind == 3) {
+        ans_int_decompress(out, n, in, nbytes);
+        return;
+    }
     if (kind == 2) {
         ans_msb_decompress(out, n, in, nbytes);
         return;
@@ -122,6 +128,40 @@ size_t ref_load_prelude(const uint8_t* in, uint32_t* nfreqs_out)
     auto v = ans_load_interp(in);
     for (size_t i = 0; i < v.size(); i++) nfreqs_out[i] = v[i];
     return v.size();
+}
+
+// One block of src/pseudo_adaptive.cpp's run<t_compressor>() (:85-130): the bytes that harness writes for the
+// block at enc_ptr -- u32 alphabet size, u32 universe, interpolative code of the running sums of the
+// block's distinct values (:106-113), then t_compressor::encode of the block remapped to 1-based ranks
+// (:91-103,115-123; skipped when the block has one distinct value).  The statements are the harness's,
+// re-typed around the UNMODIFIED interpolative_internal::encode and codec functions (the harness itself
+// needs Boost and cannot be built here).  Returns total bytes; *hdr_bytes = 8 + interpolative bytes.
+size_t ref_pa_encode(int kind, int f, const uint32_t* in_ptr, size_t block_size, uint8_t* enc_ptr, size_t enc_size,
+    size_t* hdr_bytes)
+{
+    uint32_t max_sym = *std::max_element(in_ptr, in_ptr + block_size);
+    std::vector<uint32_t> remapped_block_data(block_size);
+    std::vector<uint32_t> remapped_alphabet(size_t(max_sym) + 1, 0);
+    std::vector<uint32_t> block_alphabet;
+    for (size_t k = 0; k < block_size; k++) remapped_alphabet[in_ptr[k]] = 1;
+    if (remapped_alphabet[0] == 1) block_alphabet.push_back(0);
+    for (size_t k = 1; k <= max_sym; k++) {
+        if (remapped_alphabet[k] == 1) block_alphabet.push_back(k);
+        remapped_alphabet[k] += remapped_alphabet[k - 1];
+    }
+    for (size_t k = 0; k < block_size; k++) remapped_block_data[k] = remapped_alphabet[in_ptr[k]];
+    for (size_t k = 1; k < block_alphabet.size(); k++) block_alphabet[k] += block_alphabet[k - 1];
+    uint32_t* enc_ptr_u32 = (uint32_t*)enc_ptr;
+    *enc_ptr_u32++ = block_alphabet.size();
+    *enc_ptr_u32++ = block_alphabet.back() + 1;
+    auto bytes_written = interpolative_internal::encode(
+        enc_ptr_u32, block_alphabet.data(), block_alphabet.size(), block_alphabet.back() + 1);
+    enc_ptr += (bytes_written + 8);
+    enc_size -= (bytes_written + 8);
+    size_t total = bytes_written + 8;
+    if (hdr_bytes) *hdr_bytes = total;
+    if (block_alphabet.size() != 1) total += ref_encode(kind, f, remapped_block_data.data(), block_size, enc_ptr, enc_size);
+    return total;
 }
 
 uint32_t ref_fold_mapping(int f, uint32_t x)

@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
-FOLD, RFOLD, MSB = 0, 1, 2
+FOLD, RFOLD, MSB, INT = 0, 1, 2, 3
 
 
 class OracleInfo(C.Structure):
@@ -28,6 +28,11 @@ class OracleInfo(C.Structure):
         ("sigma", C.c_uint64),
         ("final_states", C.c_uint64 * 4),
     ]
+
+
+class PaInfo(C.Structure):
+    _fields_ = [("sigma", C.c_uint32), ("universe", C.c_uint32), ("header_bytes", C.c_uint32),
+                ("interp_bits", C.c_uint32)]
 
 
 def build_oracle():
@@ -61,6 +66,14 @@ def _load_oracle():
                                       C.POINTER(C.c_size_t)]
     lib.ans_oracle_decode.restype = C.c_int
     lib.ans_oracle_decode.argtypes = [C.c_int, C.c_uint32, _u8p, C.c_size_t, _u32p, C.c_size_t, C.c_int]
+    lib.ans_oracle_adjust_freqs_ex.restype = C.c_uint64
+    lib.ans_oracle_adjust_freqs_ex.argtypes = [_u64p, C.c_size_t, C.c_uint32, _u32p, C.c_int]
+    lib.ans_oracle_pa_encode.restype = C.c_size_t
+    lib.ans_oracle_pa_encode.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_size_t, _u8p, C.c_size_t,
+                                         C.POINTER(PaInfo), C.POINTER(OracleInfo), C.c_size_t, C.c_void_p,
+                                         C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.ans_oracle_pa_decode.restype = C.c_int
+    lib.ans_oracle_pa_decode.argtypes = [C.c_int, C.c_uint32, _u8p, C.c_size_t, _u32p, C.c_size_t]
     lib.ans_oracle_bound.restype = C.c_size_t
     lib.ans_oracle_bound.argtypes = [C.c_int, C.c_uint32, C.c_size_t]
     return lib
@@ -81,6 +94,9 @@ def _load_ref(name="libans_ref.so"):
     lib.ref_serialize_prelude.argtypes = [_u32p, C.c_size_t, C.c_uint64, _u8p]
     lib.ref_load_prelude.restype = C.c_size_t
     lib.ref_load_prelude.argtypes = [_u8p, _u32p]
+    if hasattr(lib, "ref_pa_encode"):
+        lib.ref_pa_encode.restype = C.c_size_t
+        lib.ref_pa_encode.argtypes = [C.c_int, C.c_int, _u32p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     for fn in ("ref_fold_mapping", "ref_fold_undo_mapping", "ref_fold_exception_bytes"):
         getattr(lib, fn).restype = C.c_uint32
         getattr(lib, fn).argtypes = [C.c_int, C.c_uint32]
@@ -138,6 +154,60 @@ def oracle_decode(kind, f, stream, n, ref_f3_compat=False):
     if rc != 0:
         raise RuntimeError("oracle decode failed rc=%d" % rc)
     return out
+
+
+def oracle_pa_encode(kind, f, data, ckpt_interval=0):
+    """pseudo_adaptive.cpp:85-130 block: returns (stream, PaInfo, OracleInfo of the codec part, ckpt states, ckpt offsets)."""
+    data = np.ascontiguousarray(data, dtype=np.uint32)
+    n = data.size
+    cap = 8 + 4 * n + 64 + oracle().ans_oracle_bound(kind, f, n)
+    out = np.zeros(cap, dtype=np.uint8)
+    pinfo, info = PaInfo(), OracleInfo()
+    nck_max = (n // ckpt_interval + 1) if ckpt_interval else 1
+    st = np.zeros((nck_max, 4), dtype=np.uint64)
+    off = np.zeros(nck_max, dtype=np.uint32)
+    nck = C.c_size_t(0)
+    nb = oracle().ans_oracle_pa_encode(kind, f, data, n, out, cap, C.byref(pinfo), C.byref(info), ckpt_interval,
+                                       st.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.byref(nck))
+    if nb == 0:
+        raise RuntimeError("oracle pa encode failed")
+    return out[:nb].copy(), pinfo, info, st[: nck.value].copy(), off[: nck.value].copy()
+
+
+def oracle_pa_decode(kind, f, stream, n):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    padded = np.concatenate([stream, np.zeros(16, dtype=np.uint8)])
+    out = np.zeros(n, dtype=np.uint32)
+    rc = oracle().ans_oracle_pa_decode(kind, f, padded, stream.size, out, n)
+    if rc != 0:
+        raise RuntimeError("oracle pa decode failed rc=%d" % rc)
+    return out
+
+
+def ref_pa_encode(kind, f, data, lib="libans_ref.so"):
+    """The bytes src/pseudo_adaptive.cpp writes for one block (oracle/ref_shim.cpp ref_pa_encode)."""
+    data = np.ascontiguousarray(data, dtype=np.uint32)
+    n = data.size
+    cap = 8 + 4 * n + 64 + oracle().ans_oracle_bound(kind, f, n) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    hb = C.c_size_t(0)
+    nb = ref(lib).ref_pa_encode(kind, f, data, n, out, cap, C.byref(hb))
+    return out[:nb].copy(), hb.value
+
+
+def canonicalize_pa(stream, pinfo, info):
+    """Zero the indeterminate padding bits of BOTH interpolative codes of a pseudo_adaptive block: the
+    alphabet header's last word and the codec prelude's last word."""
+    s = np.array(stream, dtype=np.uint8, copy=True)
+    vb = pinfo.interp_bits % 32
+    if vb != 0:
+        end = pinfo.header_bytes
+        w = int.from_bytes(s[end - 4:end].tobytes(), "little") & ((1 << vb) - 1)
+        s[end - 4:end] = np.frombuffer(w.to_bytes(4, "little"), dtype=np.uint8)
+    if pinfo.sigma != 1:
+        hb = pinfo.header_bytes
+        s[hb:] = canonicalize(s[hb:], info)
+    return s
 
 
 def ref_encode(kind, f, data, lib="libans_ref.so"):

@@ -56,6 +56,9 @@ def ctx(A, oracle_built, request):
 def codec_for(A, ctx, kind, f, **kw):
     if kind == ol.MSB:
         return A.ANSmsb(ctx=ctx, **kw)
+    if kind == ol.INT:
+        kw.pop("compact", None)
+        return A.ANSint(ctx=ctx, **kw)
     cls = A.ANSfold if kind == ol.FOLD else A.ANSrfold
     return cls(f, ctx=ctx, **kw)
 
@@ -790,3 +793,88 @@ def test_full_size_configs_roundtrip_and_spot_blocks(A, ctx, kind, f, spec):
         assert np.array_equal(parts["streams"][b], exp), (spec, b)
         k = st.shape[0]
         assert np.array_equal(parts["ckpt_off"][b][:k], off) and np.array_equal(parts["ckpt_state"][b][:k], st), (spec, b)
+
+
+PA_FAMS = ["zipf20s1.2", "uniform256", "geom0.01", "uniform20", "constant", "boundaries_small", "runs"]
+
+
+def _pa_input(fam, n, seed):
+    if fam == "boundaries_small":
+        return (ol.gen_inputs("boundaries", n, seed) % np.uint32(1 << 18)).astype(np.uint32)
+    if fam == "runs":  # long constant stretches: whole blocks with a single distinct value, low-entropy blocks
+        rng = np.random.default_rng(seed)
+        out = np.repeat(rng.integers(0, 1000, n // 3000 + 2), 3000)[:n].astype(np.uint32)
+        out[rng.integers(0, n, n // 500)] = 7
+        return out
+    d = ol.gen_inputs(fam, n, seed)
+    return (d % np.uint32(1 << 17)).astype(np.uint32) if fam == "uniform20" else d  # running sums must fit 32 bits
+
+
+@pytest.mark.parametrize("kind,f", [(ol.MSB, 0), (ol.FOLD, 1), (ol.FOLD, 3), (ol.INT, 0)])
+@pytest.mark.parametrize("fam", PA_FAMS)
+def test_compacted_blocks_match_oracle(A, ctx, kind, f, fam):
+    """Per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130): every block stream = alphabet header
+    + codec stream of the rank-remapped block, byte-identical to the oracle (itself pinned against the
+    reference's bytes in test_oracle.py); restart points; round trip."""
+    block, ckpt = (8192, 1024)
+    n = 5 * block + 777
+    data = _pa_input(fam, n, seed=41)
+    codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ckpt, compact=True)
+    cont = codec.encode(data)
+    parts = A.parse_container(cont)
+    H = parts["header"]
+    assert H.kind == (kind | 0x100) and H.nblocks == 6 and H.n == n
+    for b in range(H.nblocks):
+        blk = data[b * block:(b + 1) * block]
+        exp, pinfo, info, st, off = ol.oracle_pa_encode(kind, f, blk, ckpt_interval=ckpt)
+        got = parts["streams"][b]
+        assert got.size == exp.size and np.array_equal(got, exp), (fam, b, pinfo.sigma)
+        k = st.shape[0]
+        assert np.array_equal(parts["ckpt_off"][b][:k], off) and np.array_equal(parts["ckpt_state"][b][:k], st), (fam, b)
+    assert np.array_equal(codec.decode(cont, n), data), fam
+    # other geometries: round trip
+    for bl, ck in ((16384 if kind != ol.INT else 16380, 1024), (1024, 256), (64, 0)):
+        c2 = codec_for(A, ctx, kind, f, block_ints=bl, ckpt_interval=ck if ck else A.NO_CHECKPOINTS, compact=True)
+        m = min(n, 20 * bl + 13)
+        cont2 = c2.encode(data[:m])
+        assert np.array_equal(c2.decode(cont2, m), data[:m]), (fam, bl)
+
+
+def test_compaction_argument_and_domain_errors(A, ctx):
+    d = ol.gen_inputs("uniform24", 20000, 1)  # 16 Ki distinct values around 2^23: their sum exceeds 32 bits
+    with pytest.raises(A.AnsxError) as ei:
+        A.ANSmsb(ctx=ctx, compact=True).encode(d)
+    assert ei.value.status == 6
+    with pytest.raises(A.AnsxError):
+        A.ANSrfold(1, ctx=ctx, compact=True).encode(d[:100])          # rfold brings its own remap
+    with pytest.raises(A.AnsxError):
+        A.ANSint(ctx=ctx, block_ints=16384).encode(d[:100])          # ranks are 1-based: 16380 at most
+    with pytest.raises(A.AnsxError):
+        A.ANSmsb(ctx=ctx, compact=True, block_ints=32768).encode(d[:100])
+    small = (d % np.uint32(4096)).astype(np.uint32)
+    codec = A.ANSint(ctx=ctx)
+    assert codec.name() == "ANS"                                     # methods.hpp:485
+    cont = codec.encode(small)
+    assert np.array_equal(codec.decode(cont, small.size), small)
+    bad = cont.copy()
+    bad[A.parse_container(cont)["header"].payload_offset] ^= 0x5A    # alphabet size of block 0
+    with pytest.raises(A.AnsxError):
+        codec.decode(bad, small.size)
+
+
+def test_golden_compaction_fixtures(A, ctx):
+    """tests/golden/pa.json: bytes made by the real reference (pseudo_adaptive blocks); the GPU container of a
+    one-block list holds exactly that stream."""
+    with open(os.path.join(GOLD, "pa.json")) as fh:
+        gold = [e for e in json.load(fh) if e["mode"] == "pa"]
+    kinds = {"fold": ol.FOLD, "msb": ol.MSB, "int": ol.INT}
+    for e in gold:
+        d = ol.gen_inputs(e["family"], e["n"], e["seed"])
+        block = 16380 if e["kind"] == "int" else 16384
+        codec = codec_for(A, ctx, kinds[e["kind"]], e["f"], block_ints=block, ckpt_interval=A.NO_CHECKPOINTS, compact=True)
+        cont = codec.encode(d)
+        stream = A.parse_container(cont)["streams"][0]
+        tag = (e["kind"], e["f"], e["family"], e["n"])
+        assert stream.size == e["stream_len"], tag
+        assert hashlib.sha256(stream.tobytes()).hexdigest() == e["stream_sha256"], tag
+        assert np.array_equal(codec.decode(cont, e["n"]), d), tag

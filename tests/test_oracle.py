@@ -284,3 +284,63 @@ def test_msb_streams_vs_reference():
                 assert len(r) == len(s) and np.array_equal(ol.canonicalize(r, info), s), (fam, n, libname)
             assert np.array_equal(ol.ref_decode(ol.MSB, 0, s, n), d)
             assert np.array_equal(ol.oracle_decode(ol.MSB, 0, s, n), d)
+
+
+# ---------------------------------------------------------------- ANSint and pseudo_adaptive blocks
+
+@needs_ref
+def test_ansint_matches_reference():
+    """ANSint (ans_int.hpp, methods.hpp:484-497): identity symbols, 32-bit frequencies, no u16 exit."""
+    rng = np.random.default_rng(3)
+    cases = [ol.gen_inputs("uniform256", 5000, 1), ol.gen_inputs("geom0.01", 20000, 2), ol.gen_inputs("geom0.4", 7, 3),
+             np.minimum(ol.gen_inputs("zipf20s1.2", 30000, 4), 30000).astype(np.uint32),
+             np.concatenate([np.ones(299990, dtype=np.uint32), np.arange(2, 12, dtype=np.uint32)]),  # frame above 2^16
+             np.array([3] * 4000 + [1], dtype=np.uint32), np.array([5, 1], dtype=np.uint32),
+             rng.integers(1, 2000, 2001).astype(np.uint32)]
+    big = 0
+    for d in cases:
+        s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+        r = ol.ref_encode(ol.INT, 0, d)
+        assert np.array_equal(ol.canonicalize(r, info), s), d[:8]
+        assert np.array_equal(ol.oracle_decode(ol.INT, 0, s, d.size), d)
+        assert np.array_equal(ol.ref_decode(ol.INT, 0, s, d.size), d)
+        big += info.log2_frame > 16
+    assert big >= 1  # the wide-frequency regime is covered
+
+
+@needs_ref
+@pytest.mark.parametrize("kind,f", [(ol.MSB, 0), (ol.INT, 0), (ol.FOLD, 1), (ol.FOLD, 3)])
+def test_pseudo_adaptive_block_matches_reference(kind, f):
+    """One block of src/pseudo_adaptive.cpp:85-130: alphabet header + codec stream of the rank-remapped block."""
+    for fam, n in (("zipf20s1.2", 16384), ("uniform256", 4096), ("geom0.01", 8192), ("sparse_large", 3000),
+                   ("constant", 1000), ("boundaries", 513), ("uniform20", 2048), ("zipf20s1.2", 3)):
+        d = ol.gen_inputs(fam, n, seed=7)
+        if fam == "sparse_large":
+            d = d % np.uint32(1 << 20)  # the harness keeps the running sums of distinct values in 32 bits
+        s, pinfo, info, _, _ = ol.oracle_pa_encode(kind, f, d)
+        r, hb = ol.ref_pa_encode(kind, f, d)
+        assert hb == pinfo.header_bytes and r.size == s.size, (fam, n)
+        assert np.array_equal(ol.canonicalize_pa(r, pinfo, info), s), (fam, n)
+        assert np.array_equal(ol.oracle_pa_decode(kind, f, s, n), d), (fam, n)
+        assert pinfo.sigma == np.unique(d).size
+
+
+def test_golden_compaction_and_ansint():
+    """tests/golden/pa.json (made from oracle/_ref by make_pa_golden.py): pseudo_adaptive blocks for ANSmsb /
+    ANSint / ANSfold and plain ANSint streams."""
+    gold = _load("pa.json")
+    assert len(gold) > 100
+    kinds = {"fold": ol.FOLD, "msb": ol.MSB, "int": ol.INT}
+    for e in gold:
+        d = ol.gen_inputs(e["family"], e["n"], e["seed"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == e["input_sha256"], "generator drifted"
+        tag = (e["mode"], e["kind"], e["f"], e["family"], e["n"])
+        if e["mode"] == "pa":
+            s, pinfo, info, _, _ = ol.oracle_pa_encode(kinds[e["kind"]], e["f"], d)
+            assert len(s) == e["stream_len"] and pinfo.sigma == e["sigma"] and pinfo.header_bytes == e["header_bytes"], tag
+            assert hashlib.sha256(s.tobytes()).hexdigest() == e["stream_sha256"], tag
+            assert np.array_equal(ol.oracle_pa_decode(kinds[e["kind"]], e["f"], s, e["n"]), d), tag
+        else:
+            s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+            assert len(s) == e["stream_len"], tag
+            assert hashlib.sha256(ol.canonicalize(s, info).tobytes()).hexdigest() == e["stream_sha256"], tag

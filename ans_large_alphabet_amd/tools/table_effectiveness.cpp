@@ -68,7 +68,9 @@ int main(int argc, char const* argv[])
     std::vector<std::vector<uint32_t>> inputs = load_inputs(input, text);
     try {
         if (!stream) {
+            run<ANSintGPU>(inputs);         // "ANS" (table_effectiveness.cpp:145), per-block compacted alphabet
             run<ANSmsbGPU>(inputs);
+            run<ANSmsbGPUCompact>(inputs);  // the pseudo_adaptive.cpp pairing (:253-254)
             run<ANSfoldGPU<1>>(inputs);
             run<ANSfoldGPU<2>>(inputs);
             run<ANSfoldGPU<3>>(inputs);

@@ -181,15 +181,23 @@ def kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_byt
     return kernels, roofline
 
 
+def make_codec(A, ctx, codec_name, fidelity, block=0, ckpt=0, compact=False):
+    if codec_name == "int":
+        return A.ANSint(ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    if codec_name == "msb":
+        return A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt, compact=compact)
+    cls = A.ANSfold if codec_name == "fold" else A.ANSrfold
+    return cls(fidelity, ctx=ctx, block_ints=block, ckpt_interval=ckpt, compact=compact)
+
+
 def workload_string(codec_name, f, n, spec, block, ckpt):
     return "ANS%s-%d, %d ints, %s, block %d, ckpt %d" % (codec_name, f, n, spec, block, ckpt)
 
 
 def run_single(torch, A, ctx, device, codec_name, fidelity, spec, n, steps, warmup, block=0, ckpt=0, d_in=None,
-               seed=SEED, cpu_sample=0):
+               seed=SEED, cpu_sample=0, compact=False):
     """One single-GPU configuration: timed encode+decode steps, round trip, per-kernel pass."""
-    cls = A.ANSfold if codec_name == "fold" else A.ANSrfold
-    codec = cls(fidelity, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    codec = make_codec(A, ctx, codec_name, fidelity, block, ckpt, compact)
     if d_in is None:
         d_in = gen_input(torch, A, ctx, spec, n, seed, device)
     cap = min(codec.bound(n), 8 * n + (64 << 20))
@@ -267,7 +275,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", "--ints", dest="n", type=int, default=256 * (1 << 20), help="ints per GPU")
-    ap.add_argument("--codec", default="fold", choices=["fold", "rfold"])
+    ap.add_argument("--codec", default="fold", choices=["fold", "rfold", "msb", "int"])
+    ap.add_argument("--compact", action="store_true",
+                    help="per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130); implied by --codec int")
     ap.add_argument("--fidelity", type=int, default=1)
     ap.add_argument("--dist", default="zipf20s1.2", help="zipf<log2 n>[s<q>] | uniform<lo>-<hi> | uniform256 | geom<p>")
     ap.add_argument("--block", type=int, default=0, help="ints per block (0 = library default)")
@@ -310,11 +320,10 @@ def main():
     import ans_large_alphabet_amd as A
 
     ctx = A.Context(local_rank)
-    cls = A.ANSfold if args.codec == "fold" else A.ANSrfold
-    codec = cls(args.fidelity, ctx=ctx, block_ints=args.block, ckpt_interval=args.ckpt)
-    kind = A.FOLD if args.codec == "fold" else A.RFOLD
+    codec = make_codec(A, ctx, args.codec, args.fidelity, args.block, args.ckpt, args.compact)
+    kind = {"fold": A.FOLD, "rfold": A.RFOLD, "msb": A.MSB, "int": A.INT}[args.codec]
     n = args.n
-    block_ints = args.block or A.DEFAULT_BLOCK_INTS
+    block_ints = args.block or (8192 if args.codec == "int" else A.DEFAULT_BLOCK_INTS)
     if world > 1 and n % block_ints:
         raise SystemExit("N > 1: ints per GPU must be a multiple of the block size (whole blocks per rank)")
 
@@ -471,7 +480,7 @@ def main():
         kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.compact and args.codec != "int":
         m = min(n, args.cpu_sample)
         sample = d_in[:m].cpu().numpy().view("uint32")
         cpu = cpu_baseline(sample, kind, args.fidelity, block_ints)
@@ -518,6 +527,7 @@ def main():
                                    % (args.codec, args.fidelity, n, args.dist, block_ints,
                                       args.ckpt or A.DEFAULT_CKPT_INTERVAL),
                        "ints_per_gpu": n, "distribution": args.dist, "codec": codec.name(),
+                       "alphabet_compaction": bool(args.compact or args.codec == "int"),
                        "generator": "ansx_generate_dev (counter-based, seed %d, rank r draws indices [r n, (r+1) n))" % SEED,
                        "block_ints": block_ints, "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
                        "multi_gpu": ("contiguous block ranges per rank; per step every rank sends its container (fixed %d-byte "

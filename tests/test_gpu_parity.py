@@ -538,6 +538,18 @@ def test_harnesses_run_and_stream_bits_equal_the_reference(A, ctx, tmp_path):
     eff = subprocess.run([os.path.join(tools, "table_efficiency.x"), "-i", str(tmp_path), "--bits"],
                          check=True, capture_output=True, text=True).stdout
     assert "\\method{ANSfold-1}" in eff and "\\method{ANSrfold-5}" in eff and "bits/int" in eff
+    # -t: the same lists as decimal text, one number per line (util.hpp:160-170): identical bits/int columns
+    tdir = tmp_path / "text"
+    tdir.mkdir()
+    for name, arr in files.items():
+        np.savetxt(str(tdir / name.replace(".u32", ".txt")), arr.astype(np.uint32), fmt="%u")
+    out_t = subprocess.run([os.path.join(tools, "table_effectiveness.x"), "-t", "-i", str(tdir), "--stream"],
+                           check=True, capture_output=True, text=True).stdout
+    assert out_t == out
+    # the compacted codecs ("ANS" = ANSint, ANSmsb with per-block alphabets) run and verify their round trips
+    blocked = subprocess.run([os.path.join(tools, "table_effectiveness.x"), "-i", str(tmp_path)],
+                             check=True, capture_output=True, text=True).stdout
+    assert re.search(r"^ANS\s+&$", blocked, re.M) and "ANSmsb" in blocked
 
 
 def test_default_stream_ordering_without_synchronize(A, ctx):

@@ -190,10 +190,12 @@ def parse_container(buf):
     ck_off = np.frombuffer(buf[ck_off_off: ck_off_off + 4 * nck].tobytes(), dtype=np.uint32)
     ck_state_off = (ck_off_off + 4 * nck + 7) // 8 * 8
     ck_state = np.frombuffer(buf[ck_state_off: ck_state_off + 32 * nck].tobytes(), dtype=np.uint64)
+    hint_off = (ck_state_off + 32 * nck + 15) // 16 * 16
+    hints = np.frombuffer(buf[hint_off: hint_off + 32 * nb].tobytes(), dtype=np.uint32).reshape(nb, 8)
     p0 = int(H.payload_offset)
     streams = [buf[p0 + int(boff[i]): p0 + int(boff[i + 1])] for i in range(nb)]
     return {
-        "header": H, "block_off": boff, "streams": streams,
+        "header": H, "block_off": boff, "streams": streams, "parse_hints": hints,
         "ckpt_off": ck_off.reshape(nb, H.ckpts_per_block) if nck else ck_off.reshape(nb, 0),
         "ckpt_state": ck_state.reshape(nb, H.ckpts_per_block, 4) if nck else ck_state.reshape(nb, 0, 4),
     }

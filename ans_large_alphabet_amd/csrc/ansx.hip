@@ -32,7 +32,7 @@ struct ProfRec {
 };
 
 struct Layout {  // container layout, a pure function of the geometry
-    u64 index_off, ckoff_off, ckstate_off, payload_off;
+    u64 index_off, ckoff_off, ckstate_off, hint_off, payload_off;
 };
 
 }  // namespace
@@ -59,7 +59,8 @@ struct ansx_ctx {
         bool table16_fixup = false;   // ANSX_TEST_TABLE16_FIXUP: integer-state encoder fed by k_table16_from32
         bool encode_gtab16 = false;   // ANSX_ENCODE_GTAB16: force the 16-byte-entry integer-state encoder
         bool parse_generic = false;   // ANSX_PARSE_GENERIC: generic prelude parser kernel
-        bool parse_win = false;       // ANSX_PARSE_WIN: the windowed parser even where the E-array fast loop applies
+        bool parse_win = false;       // ANSX_PARSE_WIN: one lane per block, windowed parser (ignores the parse hints)
+        bool parse_fast = false;      // ANSX_PARSE_FAST: one lane per block, E-array fast loop where it applies
         bool decode_table = false;    // ANSX_DECODE_TABLE: slot -> symbol decoder tables
         bool no_stream_lds = false;   // ANSX_NO_STREAM_LDS: staged decoder reads the stream from HBM
         int decode_mode = 0;          // ANSX_DECODE_MODE: 0 auto, 1 "ring", 2 "staged"
@@ -203,8 +204,9 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     L.index_off = sizeof(ansx_container_header);
     L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
     L.ckstate_off = rup(L.ckoff_off + 4 * (u64)g.nblocks * g.nckf, 8);
-    L.payload_off = rup(L.ckstate_off + 32 * (u64)g.nblocks * g.nckf, 16);
-    if (P->plain) L.index_off = L.ckoff_off = L.ckstate_off = L.payload_off = 0;
+    L.hint_off = rup(L.ckstate_off + 32 * (u64)g.nblocks * g.nckf, 16);  // 8 x u32 parse hints per block
+    L.payload_off = L.hint_off + 32 * (u64)g.nblocks;
+    if (P->plain) L.index_off = L.ckoff_off = L.ckstate_off = L.hint_off = L.payload_off = 0;
     P->lay = L;
     return ANSX_OK;
 }
@@ -402,21 +404,22 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     if (!always16 && (max_logM > 16 || test_fixup))  // mixed call: a frame above 2^16 sends every block to the integer-state encoder
         LAUNCH(c, "k_table16_from32", k_table16_from32, NB, 256, 0, s, g, NSP, (const ansx_blk*)blk,
             (const u32*)c->tab32.p, (ansx_enc_entry*)c->table.p);
-    // K3
+    // K3 (also fills the container's parse hints)
+    u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
     if (NSP <= 1024 && max_logM <= 16) {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq);
+            (u64)scr_stride, mostfreq, hints);
     } else if (NSP <= 4096 && max_logM <= 16) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)((size_t)NSP * 12 + 64)));
         LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq);
+            (u64)scr_stride, mostfreq, hints);
     } else {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq);
+            (u64)scr_stride, mostfreq, hints);
     }
     // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
     // alphabet / frame actually produced, read back above).
@@ -551,13 +554,13 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
             HIPCHK(c, hipFuncSetAttribute((const void*)k_model_fused<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML.total));
         LAUNCH(c, "k_model_fused", (k_model_fused<4>), NB, 256, ML.total, s, src, g, NSP, ML,
             (const ansx_log2_ent*)c->log2lut.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq,
-            gflags, 1u << 30);
+            gflags, 1u << 30, (u32*)(d_out + P.lay.hint_off));
     } else {
         if (ML.total > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_model_fused<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML.total));
         LAUNCH(c, "k_model_fused", (k_model_fused<16>), NB, 256, ML.total, s, src, g, NSP, ML,
             (const ansx_log2_ent*)c->log2lut.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq,
-            gflags, 1u << 30);
+            gflags, 1u << 30, (u32*)(d_out + P.lay.hint_off));
     }
     u64* ck_state = (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = (u32*)(d_out + P.lay.ckoff_off);
@@ -645,26 +648,33 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info)
+    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info, const u32* hints)
 {
     const u32 T = fold_T(g.f);
     int rc;
     if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
     if ((rc = ensure(c, c->dec_info, (size_t)g.nblocks * 16))) return rc;
-    // K7: one lane per block, 64 blocks per wave.  Small alphabets (values fit 16 bits, per-lane arrays fit
-    // LDS: up to ~880 symbols): the E-array fast loop, 0.165 ms on the bench workload against 0.22 ms for the
-    // windowed parser; everything else: the windowed parser (any alphabet / frame size; 0.88 ms on 2300-symbol
-    // alphabets against 1.05 ms for the generic kernel it replaces).  ANSX_PARSE_WIN / ANSX_PARSE_GENERIC
-    // force the other forms (cross-checks in the tests).
+    // K7.  Containers carry parse hints (bit offsets of the top subtrees of every block's interpolative code):
+    // eight lanes per block, k_parse_prelude_par.  Without hints (single-stream mode) or on request one lane
+    // per block: the windowed parser (any alphabet / frame size; ANSX_PARSE_WIN), the older E-array fast loop
+    // (ANSX_PARSE_FAST: 16-bit values, up to ~880 symbols) or the generic kernel (ANSX_PARSE_GENERIC) --
+    // all four are cross-checked in the tests.
     const size_t pf_e = std::max<size_t>(20480, rup(((size_t)max_ns + 2) * 128, 16));
     const size_t pf_lds = pf_e + (size_t)ANSX_PF_SW * 64 * 4 + 21 * 64 * 4;
     u32 stage_words = ANSX_PF_SW;
-    if (c->dbg.parse_stage_words >= 2 && c->dbg.parse_stage_words <= ANSX_PF_SW)  // tests: force the in-kernel fallback
+    if (c->dbg.parse_stage_words >= 2 && c->dbg.parse_stage_words <= ANSX_PF_SW)  // tests: force the fast loop's in-kernel fallback
         stage_words = c->dbg.parse_stage_words & ~1u;
     if (c->dbg.parse_generic) {
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
             boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
-    } else if (!c->dbg.parse_win && (u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024) {
+    } else if (hints != nullptr && !c->dbg.parse_win && !c->dbg.parse_fast) {
+        if (max_ns <= 1024)
+            LAUNCH(c, "k_parse_prelude", (k_parse_prelude_par<RF, 64>), (g.nblocks + 7) / 8, 64, 0, s, cont, g, NSP, boff,
+                payload_off, max_ns, maxM, hints, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
+        else
+            LAUNCH(c, "k_parse_prelude", (k_parse_prelude_par<RF, 32>), (g.nblocks + 7) / 8, 64, 0, s, cont, g, NSP, boff,
+                payload_off, max_ns, maxM, hints, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
+    } else if (c->dbg.parse_fast && (u64)maxM + max_ns + 3 <= 65535u && pf_lds <= 150 * 1024) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_parse_prelude_fast<RF>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_lds));
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude_fast<RF>), (g.nblocks + 63) / 64, 64, pf_lds, s, cont, g,
@@ -798,7 +808,7 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     if (bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
     ansx_container_header H;
     memcpy(&H, h, sizeof(H));
-    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
+    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
     if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
     const u32 k = H.kind & 0xFFu;  // bit 8: per-block alphabet compaction
     if ((H.kind & ~0x1FFu) || k > 3 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
@@ -908,6 +918,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
         max_block_bytes = c->h_pin[ANSX_G_PAD];
     }
+    const u32* hints = P.plain ? nullptr : (const u32*)(d_in + P.lay.hint_off);
     const uint4* pa_info = nullptr;
     if (P.g.pa) {  // alphabet headers first: they tell where every block's codec stream starts
         if ((rc = ensure(c, c->pa_alpha, (size_t)P.g.nblocks * P.g.block_ints * 4))) return rc;
@@ -918,10 +929,10 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints);
     if (rc) return rc;
     if (P.g.pa)
         LAUNCH(c, "k_pa_unmap", k_pa_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, pa_info, d_out, gflags);
@@ -960,7 +971,7 @@ int ansx_init(int device, ansx_ctx** out)
         delete c;
         return ANSX_ERR_HIP;
     }
-    static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN",
+    static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN", "ANSX_PARSE_FAST",
         "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
@@ -983,6 +994,7 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_ENCODE_GTAB16")) c->dbg.encode_gtab16 = on;
     else if (!strcmp(name, "ANSX_PARSE_GENERIC")) c->dbg.parse_generic = on;
     else if (!strcmp(name, "ANSX_PARSE_WIN")) c->dbg.parse_win = on;
+    else if (!strcmp(name, "ANSX_PARSE_FAST")) c->dbg.parse_fast = on;
     else if (!strcmp(name, "ANSX_DECODE_TABLE")) c->dbg.decode_table = on;
     else if (!strcmp(name, "ANSX_NO_STREAM_LDS")) c->dbg.no_stream_lds = on;
     else if (!strcmp(name, "ANSX_MODEL_FUSED")) c->dbg.model_fused = on;
@@ -1171,6 +1183,7 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
     D.nckf = P.g.nckf;
     D.ckoff_off = P.lay.ckoff_off;
     D.ckstate_off = P.lay.ckstate_off;
+    D.hint_off = P.lay.hint_off;
     D.payload_off = P.lay.payload_off;
     // header, final index entry, alignment padding: written from the host image
     HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
@@ -1189,7 +1202,7 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
     for (int i = 0; i < nparts; i++) {
         const u64 nb_ = D.part[i].nblocks;
         const u64 pieces = (8 * nb_ + 65535) / 65536 + (4 * nb_ * D.nckf + 65535) / 65536 + (32 * nb_ * D.nckf + 65535) / 65536
-            + (D.part[i].payload_bytes + 65535) / 65536;
+            + (32 * nb_ + 65535) / 65536 + (D.part[i].payload_bytes + 65535) / 65536;
         max_pieces = std::max(max_pieces, pieces);
     }
     prof_begin(c, "k_merge_containers", s);

@@ -836,7 +836,7 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
 template <int IPT, bool PA = false>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
     u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
-    u64 uni = 0)
+    u64 uni = 0, u32* __restrict__ hints = nullptr)
 {
     constexpr bool SMALL = IPT > 0;
     const u64 u = PA ? uni : ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
@@ -873,6 +873,33 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
     const u32 nwords = (total_bits + 31) >> 5;
     for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
     __syncthreads();
+    if (!PA && hints != nullptr && tid < 8) {
+        // Parse hints for the container index: where the decoder may enter this code in parallel.  The code
+        // is a pre-order walk, so the right subtree of a node (pre-order rank r, n items) begins at the
+        // item of rank r + h, h = (n + 1) / 2; off[] holds every item's bit offset by rank.  hints[0] = valid
+        // bits, hints[1 + i] = offset of the right subtree of top node i (first three levels, breadth
+        // first: children of i are 2i + 1, 2i + 2), 0 where it is empty.
+        u32 hv = total_bits;
+        if (tid >= 1) {
+            const u32 node = tid - 1;  // 0 .. 6
+            u32 r = 0, n = ns;
+            // path from the root: bits of (node + 1) below its leading one, most significant first
+            const u32 depth = 31 - __clz(node + 1);
+            for (u32 k = depth; k-- > 0;) {
+                const u32 h = (n + 1) >> 1;
+                if ((((node + 1) >> k) & 1u) == 0) {  // left child
+                    r = r + 1;
+                    n = n ? h - 1 : 0;
+                } else {  // right child
+                    r = r + h;
+                    n = n ? n - h : 0;
+                }
+            }
+            const u32 h = (n + 1) >> 1;
+            hv = (n != 0 && n - h != 0) ? off[r + h] : 0u;
+        }
+        hints[(u64)b * 8 + tid] = hv;
+    }
     auto place = [&](const ansx_code& c) {
         if (c.len) {
             u32 o = off[c.rank];
@@ -940,7 +967,8 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
 template <int IPT>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
-    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq)
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
+    u32* __restrict__ hints)
 {
     constexpr bool SMALL = IPT > 0;
     extern __shared__ u32 lds32[];
@@ -974,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         __threadfence_block();
     }
     __syncthreads();
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid);
+    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1517,7 +1545,7 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // ansx_container_header, little endian (include/ansx.h)
-    const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '1', 0, 0 };
+    const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
     for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
     u32* w = (u32*)(out + 8);
     w[0] = g.kind | (g.pa ? 0x100u : 0u);  // bit 8: per-block alphabet compaction
@@ -1811,54 +1839,38 @@ __global__ __launch_bounds__(64) void k_parse_prelude_fast(const u8* __restrict_
 }
 
 // ---- K7, windowed form: any alphabet / frame size.
-// One lane per block again, but no per-symbol LDS array: a node's bounds travel WITH the node (the
-// pending right subtrees sit on an LDS stack as (start | size, low, high) in three lane-major arrays, and
-// the top entry is mirrored in registers, so a pop takes its node from registers and only refreshes the
-// mirror), and the bit stream is read through three consecutive 32-bit words held in registers plus one
-// prefetched word: an item takes its <= 31 + 1 bits from one v_alignbit of two of them, and at most one
-// word boundary is crossed per item.  The words come from an LDS window of SW words per lane, staged
-// from the stream and re-staged FOR EVERY LANE as soon as one lane gets near its end (lanes progress at
-// about the same rate, so a wave re-stages once per ~SW words, not once per lane), so a prelude may be
-// arbitrarily long.  The item body is straight-line code under a per-lane predicate: finished or
-// malformed lanes keep their state frozen.
-template <bool RFOLD, u32 SW>
-__global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
-    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
-    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
+// One lane per (sub)tree, no per-symbol LDS array: a node's bounds travel WITH the node (the pending right
+// subtrees sit on an LDS stack as (start | size, low, high) in three lane-major arrays, and the top entry
+// is mirrored in registers, so a pop takes its node from registers and only refreshes the mirror), and the
+// bit stream is read through three consecutive 32-bit words held in registers plus one prefetched word: an
+// item takes its <= 31 + 1 bits from one v_alignbit of two of them, and at most one word boundary is
+// crossed per item.  The words come from an LDS window of SW words per lane, staged from the stream and
+// re-staged FOR EVERY LANE as soon as one lane gets near its end (lanes progress at about the same rate,
+// so a wave re-stages once per ~SW words, not once per lane), so a code may be arbitrarily long.  The item
+// body is straight-line code under a per-lane predicate: finished or malformed lanes keep their state
+// frozen.  parse_subtree_win decodes the `n` items of the subtree rooted at items [a, a + n) with value
+// bounds [low, high], whose code starts at bit `bitpos` of the interpolative words at bp; every lane of
+// the wave must call it (lanes with nothing to do pass n = 0).  Returns the lane's error flag.
+template <u32 SW, u32 STK>
+__device__ __forceinline__ u32 parse_subtree_win(u32 (*stage)[64], u32 (*stkA)[64], u32 (*stkL)[64], u32 (*stkH)[64],
+    u32 lane, const u8* __restrict__ bp, u32 avail_words, u32 u, u32 a, u32 n, u32 low, u32 high, u32 bitpos,
+    u32 err, u32* __restrict__ cum)
 {
-    extern __shared__ u32 pw_lds[];
-    u32(*stage)[64] = (u32(*)[64])pw_lds;                       // [SW][64]
-    u32(*stkA)[64] = (u32(*)[64])(pw_lds + SW * 64);            // [24][64] start | size << 16
-    u32(*stkL)[64] = stkA + 24;                                 // low bound of the pending subtree
-    u32(*stkH)[64] = stkL + 24;                                 // high bound; row 23 of each = dump
-    const u32 lane = threadIdx.x;
-    const u32 b = blockIdx.x * 64 + lane;
-    const bool live = b < g.nblocks;
-    parse_hdr H;
-    H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;
-    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
-    const u32 herr = H.err;  // 2: compaction, no codec stream to parse (not an error of this kernel)
-    u32 err = H.err;
-    const u32 ns = err ? 0u : H.ns;
-    const u8* bp = H.stream + H.pos;                                  // interpolative words start here
-    const u32 avail_words = err ? 0u : (H.sbytes - H.pos) >> 2;       // whole words inside the block stream
+    const u32 cnt = err ? 0u : n;  // items of this lane
     const u32 maxbits = avail_words * 32;
-    const u32 u = (1u << H.logM) + ns + 1;                            // universe (ans_util.hpp:60), < 2^31
-    u32* cum = g_cum + (u64)(live ? b : 0) * (NSP + 8);
-    u32 a = 0, n = ns, low = 1, high = u + 1;   // current node: items [a, a + n), values in [low, high]
-    u32 ta = 0, tl = 0, th = 0;                 // register mirror of the stack's top entry
-    u32 sp = 0, bitpos = 0, done = 0;
-    u32 base_w = 0;                             // stream word held in stage[0][lane]
-    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;         // words wi, wi + 1, wi + 2 (wi = bitpos >> 5), prefetched wi + 3
+    u32 ta = 0, tl = 0, th = 0;     // register mirror of the stack's top entry
+    u32 sp = 0, done = 0;
+    u32 base_w = 0;                 // stream word held in stage[0][lane]
+    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // words wi, wi + 1, wi + 2 (wi = bitpos >> 5), prefetched wi + 3
     bool trigger = true;
     for (;;) {
-        const bool pending = !err && done < ns;
+        const bool pending = !err && done < cnt;
         if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
         if (trigger) {
             // (re)stage every unfinished lane's next SW words from its current word on
             if (pending) base_w = bitpos >> 5;
             wave_lds_sync();
-#pragma unroll 4
+#pragma unroll 8
             for (u32 j = 0; j < SW / 2; j++) {
                 const u32 w = base_w + 2 * j;
                 u64 v = 0;
@@ -1872,9 +1884,9 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
             trigger = false;
         }
         for (;;) {
-            const bool act = !err && done < ns;
+            const bool act = !err && done < cnt;
             if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-            // node shape (a function of ns alone)
+            // node shape (a function of the subtree size alone)
             const u32 h = (n + 1) >> 1;
             const u32 n1 = h - 1, n2 = n - h, pe = a + h;
             // this item (read_center_mid, interp.hpp:47-63)
@@ -1901,7 +1913,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
             const bool push = go && caseA && n2 != 0;
             const bool pop = go && !caseA && !caseB;
             if (go) cum[pe] = v - 1;  // inc[pe - 1]
-            const u32 srow = push ? sp : 23u;
+            const u32 srow = push ? sp : STK - 1;
             stkA[srow][lane] = pe | (n2 << 16);  // start, size < 2^15 (alphabets <= 16384 slots)
             stkL[srow][lane] = v + 1;
             stkH[srow][lane] = high;
@@ -1919,7 +1931,7 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
             sp = sp + (push ? 1u : 0u) - ((pop && sp) ? 1u : 0u);
             // after a pop the entry below becomes the top: fetch it for the mirror (used at the NEXT pop
             // at the earliest)
-            const u32 below = sp ? sp - 1 : 23u;
+            const u32 below = sp ? sp - 1 : STK - 1;
             const u32 ra = stkA[below][lane], rl = stkL[below][lane], rh = stkH[below][lane];
             if (pop) {
                 ta = ra, tl = rl, th = rh;
@@ -1933,16 +1945,142 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
             const u32 rel = (nbit >> 5) - base_w;
             w3 = stage[rel + 3 < SW ? rel + 3 : SW - 1][lane];
             // near the end of the staged words: every lane re-stages before the next item
-            if (__builtin_amdgcn_ballot_w64(go && done < ns && rel + 5 >= SW) != 0) {
+            if (__builtin_amdgcn_ballot_w64(go && done < cnt && rel + 5 >= SW) != 0) {
                 trigger = true;
                 break;
             }
         }
         if (!trigger) break;
     }
+    return err;
+}
+
+// one lane per block (ANSX_PARSE_WIN; default for containers without usable parse hints)
+template <bool RFOLD, u32 SW>
+__global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
+{
+    extern __shared__ u32 pw_lds[];
+    u32(*stage)[64] = (u32(*)[64])pw_lds;                       // [SW][64]
+    u32(*stkA)[64] = (u32(*)[64])(pw_lds + SW * 64);            // [24][64] start | size << 16
+    u32(*stkL)[64] = stkA + 24;                                 // low bound of the pending subtree
+    u32(*stkH)[64] = stkL + 24;                                 // high bound; row 23 of each = dump
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x * 64 + lane;
+    const bool live = b < g.nblocks;
+    parse_hdr H;
+    H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;
+    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
+    const u32 herr = H.err;  // 2: compaction, no codec stream to parse (not an error of this kernel)
+    const u32 ns = herr ? 0u : H.ns;
+    const u8* bp = H.stream + H.pos;                                  // interpolative words start here
+    const u32 avail_words = herr ? 0u : (H.sbytes - H.pos) >> 2;      // whole words inside the block stream
+    const u32 u = (1u << H.logM) + ns + 1;                            // universe (ans_util.hpp:60), < 2^31
+    u32* cum = g_cum + (u64)(live ? b : 0) * (NSP + 8);
+    const u32 err = parse_subtree_win<SW, 24>(stage, stkA, stkL, stkH, lane, bp, avail_words, u, 0, ns, 1, u + 1, 0, herr, cum);
     if (live) {
         binfo[b] = make_uint4(H.ns, H.logM, H.flag, err);
         if (err && herr != 2) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
+    }
+}
+
+// ---- K7, parallel form (the default): the container index carries, per block, the bit offsets at which
+// the right subtrees of the code's top seven nodes begin (written by the prelude writer, which has every
+// item's offset anyway).  Eight lanes per block: the top three levels are decoded
+// level by level (a node needs its parent's value for its bounds; left children follow their parent in
+// the stream, right children sit at the hinted offsets), then every lane runs parse_subtree_win on one of
+// the eight depth-3 subtrees -- an eighth of the serial chain.  Hints are untrusted input like the
+// payload: offsets are bounds-checked, and a wrong one yields a table that fails the decoder's
+// consistency checks or decodes to garbage, never an out-of-range access.
+template <bool RFOLD, u32 SW>
+__global__ __launch_bounds__(64) void k_parse_prelude_par(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, const u32* __restrict__ hints,
+    u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
+{
+    // SW staged words per lane (a subtree's share of a prelude is ~35 bytes at 530 symbols, ~130 at 2300).
+    // Measured on MI355X, 16384 blocks: SW = 64 0.166 / 0.284 ms, SW = 32 0.180 / 0.262 ms for those two shapes
+    // (the kernel is VALU-issue bound machine-wide -- ~125 instructions per item -- so it gains over one
+    // lane per block only where that form leaves SIMDs idle: 3.4x on the large alphabets, nothing on the small).
+    __shared__ u32 stage[SW][64];
+    __shared__ u32 stkA[16][64], stkL[16][64], stkH[16][64];  // subtrees of <= 2048 items: depth <= 12; row 15 = dump
+    const u32 lane = threadIdx.x;
+    const u32 j = lane & 7;                      // lane within the block's group
+    const u32 b = blockIdx.x * 8 + (lane >> 3);
+    const bool live = b < g.nblocks;
+    parse_hdr H;
+    H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;
+    if (live) H = parse_header<RFOLD>(cont, g, NSP, block_off, payload_off, max_ns, maxM, b, pa_info);
+    const u32 herr = H.err;
+    const u32 ns = herr ? 0u : H.ns;
+    const u8* bp = H.stream + H.pos;
+    const u32 avail_words = herr ? 0u : (H.sbytes - H.pos) >> 2;
+    const u32 maxbits = avail_words * 32;
+    const u32 u = (1u << H.logM) + ns + 1;
+    u32* cum = g_cum + (u64)(live ? b : 0) * (NSP + 8);
+    const u32 hv = live ? hints[(u64)b * 8 + j] : 0u;   // lane j holds hint word j of its block
+    // ---- top three levels, one level per round; lane j < 2^k owns node j of level k
+    u32 a = 0, n = (j == 0) ? ns : 0u, low = 1, high = u + 1, bit = 0, err = 0;
+    for (u32 k = 0; k < 3; k++) {
+        u32 v = 0, len = 0;
+        const bool mine = j < (1u << k) && n != 0;
+        if (mine) {  // decode this node's item at `bit` (read_center_mid, interp.hpp:47-63)
+            const u32 h = (n + 1) >> 1;
+            const u32 n1 = h - 1, n2 = n - h;
+            const u32 U = high - n2 - low - n1 + 1;
+            u64 w = 0;
+            const u32 byte = bit >> 3, avail = avail_words * 4;
+            if (byte + 8 <= avail) w = ld_u64_unaligned(bp + byte);
+            else
+                for (u32 i = 0; byte + i < avail && i < 8; i++) w |= (u64)bp[byte + i] << (8 * i);
+            const u32 win = (u32)(w >> (bit & 7u));
+            const u32 Um1 = U - 1;
+            const u32 bb = 32 - __clz(Um1 | 1u) - (Um1 == 0 ? 1u : 0u);
+            const u32 lb = bb ? bb - 1 : 0;
+            const u32 m = (u32)((1ull << bb) - U);
+            const u32 dh = U - ((1u << lb) & (bb ? ~0u : 0u));
+            u32 val = (win & ((1u << lb) - 1u)) + 1;
+            const bool big = (U != 1) && (val > m);
+            val = big ? (2 * val + ((win >> lb) & 1u)) - m - 1 : val;
+            val += dh;
+            if (val > U) val -= U;
+            if (U == 1) val = 1;
+            v = low + n1 - 1 + val;
+            len = (U == 1) ? 0u : lb + (big ? 1u : 0u);
+            if (U == 0 || U > u + 1 || bit + len > maxbits) err = 1;
+            else cum[a + h] = v - 1;
+        }
+        // children: lane j' < 2^(k+1) takes child (j' & 1) of the node held by lane j' >> 1 of its group
+        const int src = (int)((lane & ~7u) | (j >> 1));
+        const u32 pa_ = (u32)__shfl((int)a, src), pn = (u32)__shfl((int)n, src), plow = (u32)__shfl((int)low, src),
+                  phigh = (u32)__shfl((int)high, src), pbit = (u32)__shfl((int)bit, src), pv = (u32)__shfl((int)v, src),
+                  plen = (u32)__shfl((int)len, src), perr = (u32)__shfl((int)err, src);
+        // hint word of the parent's right subtree: parent = node (2^k - 1) + (j >> 1) in breadth-first order
+        const u32 hword = (u32)__shfl((int)hv, (int)((lane & ~7u) | (((1u << k) + (j >> 1)) & 7u)));
+        if (j < (2u << k)) {
+            const u32 ph = (pn + 1) >> 1;
+            const bool right = (j & 1u) != 0;
+            const bool dead = pn == 0 || perr != 0;
+            a = right ? pa_ + ph : pa_;
+            n = dead ? 0u : (right ? pn - ph : ph - 1);
+            low = right ? pv + 1 : plow;
+            high = right ? phigh : pv - 1;
+            bit = right ? hword : pbit + plen;
+            err = perr;
+            if (n != 0 && bit > maxbits) err = 1;
+        }
+    }
+    // ---- the eight depth-3 subtrees
+    err = parse_subtree_win<SW, 16>(stage, stkA, stkL, stkH, lane, bp, avail_words, u, a, n, low, high, bit,
+        herr ? herr : err, cum);
+    // block verdict: any lane of the group
+    u32 e = err;
+    e |= (u32)__shfl_xor((int)e, 1);
+    e |= (u32)__shfl_xor((int)e, 2);
+    e |= (u32)__shfl_xor((int)e, 4);
+    if (live && j == 0) {
+        binfo[b] = make_uint4(H.ns, H.logM, H.flag, herr == 2 ? 2u : (e ? 1u : 0u));
+        if (e && herr != 2) atomicOr(&gflags[ANSX_G_ERR], 1u << 3 /* FORMAT */);
     }
 }
 
@@ -2538,7 +2676,7 @@ struct ansx_merge_part {
 };
 struct ansx_merge_desc {
     ansx_merge_part part[ANSX_MERGE_MAX_PARTS];
-    u64 ckoff_off, ckstate_off, payload_off;  // merged layout (index at 64)
+    u64 ckoff_off, ckstate_off, hint_off, payload_off;  // merged layout (index at 64)
     u32 nparts, nckf;
 };
 
@@ -2563,8 +2701,10 @@ __global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8*
     const u64 PIECE = 65536;
     // section sizes of this part, in the order they are walked by blockIdx.x
     const u64 idx_bytes = 8ull * P.nblocks, cko_bytes = 4ull * P.nblocks * D.nckf, cks_bytes = 32ull * P.nblocks * D.nckf;
+    const u64 hint_bytes = 32ull * P.nblocks;
     const u64 n_idx = (idx_bytes + PIECE - 1) / PIECE, n_cko = (cko_bytes + PIECE - 1) / PIECE,
-              n_cks = (cks_bytes + PIECE - 1) / PIECE, n_pay = (P.payload_bytes + PIECE - 1) / PIECE;
+              n_cks = (cks_bytes + PIECE - 1) / PIECE, n_hint = (hint_bytes + PIECE - 1) / PIECE,
+              n_pay = (P.payload_bytes + PIECE - 1) / PIECE;
     u64 piece = blockIdx.x;
     // part layout (make_plan): index at 64, restart offsets behind the nblocks + 1 index entries
     const u64 p_cko = 64 + 8ull * (P.nblocks + 1);
@@ -2590,6 +2730,13 @@ __global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8*
         return;
     }
     piece -= n_cks;
+    if (piece < n_hint) {
+        const u64 p_hint = (p_cks + cks_bytes + 15) / 16 * 16;
+        const u64 lo = piece * PIECE, len = hint_bytes - lo < PIECE ? hint_bytes - lo : PIECE;
+        merge_copy(out + D.hint_off + 32ull * P.first_block + lo, P.src + p_hint + lo, len, tid, 256);
+        return;
+    }
+    piece -= n_hint;
     if (piece < n_pay) {
         const u64 lo = piece * PIECE, len = P.payload_bytes - lo < PIECE ? P.payload_bytes - lo : PIECE;
         merge_copy(out + D.payload_off + P.pay_base + lo, P.src + P.payload_off + lo, len, tid, 256);

@@ -76,7 +76,7 @@ template <int IPT>
 __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     ansx_model_lds ML, const ansx_log2_ent* __restrict__ l2lut, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ gflags, u32 value_limit)
+    u32* __restrict__ gflags, u32 value_limit, u32* __restrict__ hints)
 {
     extern __shared__ __attribute__((aligned(16))) u8 msm[];
     __shared__ u32 sh_u[16];      // 0 max_sym, 1 sigma, 2 nbig, 3 xmax, 4 jmin, 5 sat mask, 6 chosen+2 (0 = undecided), 7 prev+1
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
     }
     __syncthreads();
     // ---- P9: prelude (rfold header, vbyte(max_sym), log2 M, interpolative code)
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid);
+    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints);
     if (tid == 0) {
         B->n = nb;
         B->max_sym = ns - 1;

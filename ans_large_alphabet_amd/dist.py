@@ -16,7 +16,7 @@ import struct
 import torch
 
 HEADER_BYTES = 64
-MAGIC = b"ANSXv1\x00\x00"
+MAGIC = b"ANSXv2\x00\x00"
 
 
 def shard_blocks(n, block_ints, rank, world):
@@ -38,8 +38,9 @@ def layout(nblocks, ckpts_per_block):
     index_off = HEADER_BYTES
     ckoff_off = index_off + 8 * (nblocks + 1)
     ckstate_off = (ckoff_off + 4 * nblocks * ckpts_per_block + 7) // 8 * 8
-    payload_off = (ckstate_off + 32 * nblocks * ckpts_per_block + 15) // 16 * 16
-    return index_off, ckoff_off, ckstate_off, payload_off
+    hint_off = (ckstate_off + 32 * nblocks * ckpts_per_block + 15) // 16 * 16  # 8 x u32 parse hints per block
+    payload_off = hint_off + 32 * nblocks
+    return index_off, ckoff_off, ckstate_off, hint_off, payload_off
 
 
 def parse_header(buf):
@@ -113,7 +114,7 @@ def merge_containers(buf, sizes):
             raise ValueError("only the last rank may end in a partial block")
     nblocks = sum(h["nblocks"] for h in hs)
     nckf = h0["ckpts_per_block"]
-    idx_off, ckoff_off, ckstate_off, payload_off = layout(nblocks, nckf)
+    idx_off, ckoff_off, ckstate_off, hint_off, payload_off = layout(nblocks, nckf)
     payload_bytes = sum(h["payload_bytes"] for h in hs)
     out = torch.zeros(payload_off + payload_bytes, dtype=torch.uint8, device=dev)
     merged = dict(h0)
@@ -124,13 +125,14 @@ def merge_containers(buf, sizes):
     blk, pay = 0, 0
     index = []
     for p, h in zip(parts, hs):
-        i_off, c_off, s_off, p_off = layout(h["nblocks"], nckf)
+        i_off, c_off, s_off, h_off, p_off = layout(h["nblocks"], nckf)
         nb = h["nblocks"]
         boff = p[i_off:i_off + 8 * (nb + 1)].clone().view(torch.int64)
         index.append(boff[:nb] + pay)
         if nckf:
             out[ckoff_off + 4 * blk * nckf: ckoff_off + 4 * (blk + nb) * nckf] = p[c_off:c_off + 4 * nb * nckf]
             out[ckstate_off + 32 * blk * nckf: ckstate_off + 32 * (blk + nb) * nckf] = p[s_off:s_off + 32 * nb * nckf]
+        out[hint_off + 32 * blk: hint_off + 32 * (blk + nb)] = p[h_off:h_off + 32 * nb]
         out[payload_off + pay: payload_off + pay + h["payload_bytes"]] = p[p_off:p_off + h["payload_bytes"]]
         blk += nb
         pay += h["payload_bytes"]

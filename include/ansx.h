@@ -198,7 +198,7 @@ int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t fir
 
 /* Test / experiment hook: select one of the equivalent internal code paths (all must produce identical
  * bytes).  Names are those of the environment variables read once by ansx_init: ANSX_DECODE_MODE
- * ("ring" | "staged" | ""), ANSX_DECODE_TABLE, ANSX_NO_STREAM_LDS, ANSX_PARSE_GENERIC, ANSX_PARSE_WIN,
+ * ("ring" | "staged" | ""), ANSX_DECODE_TABLE, ANSX_NO_STREAM_LDS, ANSX_PARSE_GENERIC, ANSX_PARSE_WIN, ANSX_PARSE_FAST,
  * ANSX_PARSE_STAGE_WORDS (number), ANSX_ENCODE_GTAB16, ANSX_TEST_TABLE16_FIXUP, ANSX_MODEL_FUSED, ANSX_MODEL_SYNC,
  * ANSX_NS_HINT (number: alphabet-size hint for every call instead of the per-geometry one the context
  * learns; too small a value only costs a repeat on the general path)

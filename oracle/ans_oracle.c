@@ -887,3 +887,36 @@ int ans_oracle_pa_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes,
     free(alpha);
     return rc;
 }
+
+
+/* ---------------------------------------------------------------- container index: parse hints */
+
+static void hints_walk(bitr* is, size_t n, uint64_t low, uint64_t high, uint32_t depth, uint32_t bfs, uint32_t* hints)
+{
+    if (n == 0) return;
+    uint64_t h = (n + 1ull) >> 1;
+    uint64_t n1 = h - 1ull;
+    uint64_t n2 = n - h;
+    uint64_t v = low + n1 - 1ull + read_center_mid(is, high - n2 - low - n1 + 1ull);
+    hints_walk(is, (size_t)n1, low, v - 1ull, depth + 1, 2 * bfs + 1, hints);
+    if (depth < 3 && n2) hints[1 + bfs] = (uint32_t)is->bitpos; /* the right subtree's first item starts here */
+    hints_walk(is, (size_t)n2, v + 1ull, high, depth + 1, 2 * bfs + 2, hints);
+}
+
+/* This build's container carries, per block, where the interpolative code of the codec prelude can be
+ * entered in parallel: hints[0] = valid bits of the code, hints[1 + i] = bit offset of
+ * the first item of the RIGHT subtree of top node i (the 7 nodes of the first three levels, breadth-first:
+ * children of i are 2i+1, 2i+2), 0 where that subtree is empty.  `prelude` points at the vbyte(max_sym). */
+void ans_oracle_prelude_hints(const uint8_t* prelude, uint32_t* hints)
+{
+    uint32_t max_sym;
+    const uint8_t* p = vbyte_get(prelude, &max_sym);
+    uint32_t lg = *p++;
+    size_t nsyms = (size_t)max_sym + 1;
+    bitr r;
+    r.in = p;
+    r.bitpos = 0;
+    for (int i = 0; i < 8; i++) hints[i] = 0;
+    hints_walk(&r, nsyms, 1, (1ull << lg) + nsyms + 1 + 1, 0, 0, hints);
+    hints[0] = (uint32_t)r.bitpos;
+}

@@ -85,6 +85,9 @@ size_t ans_oracle_pa_encode(int kind, uint32_t f, const uint32_t* in, size_t n, 
 /* Inverse of ans_oracle_pa_encode (the reference harness never decodes: this build's own). */
 int ans_oracle_pa_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes, uint32_t* out, size_t n);
 
+/* Parse hints of a codec prelude for this build's container index (8 words, see ans_oracle.c). */
+void ans_oracle_prelude_hints(const uint8_t* prelude, uint32_t* hints);
+
 /* Worst-case stream size for one encode() call. */
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n);
 

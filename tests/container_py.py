@@ -6,7 +6,7 @@ import numpy as np
 
 import oracle_lib as ol
 
-MAGIC = b"ANSXv1\x00\x00"
+MAGIC = b"ANSXv2\x00\x00"
 
 
 def nseg(nb, ckpt):
@@ -23,10 +23,11 @@ def build_container(kind, f, data, block, ckpt):
         ckpt = 0
     nblocks = (n + block - 1) // block
     nckf = nseg(block, ckpt) - 1
-    streams, cks, cko, maxlg, maxns = [], [], [], 0, 0
+    streams, cks, cko, hints, maxlg, maxns = [], [], [], [], 0, 0
     for b in range(nblocks):
         s, info, st, off = ol.oracle_encode(kind, f, data[b * block:(b + 1) * block], ckpt_interval=ckpt)
         streams.append(s)
+        hints.append(ol.prelude_hints(s, info.header_bytes))
         pad_s = np.zeros((nckf, 4), dtype=np.uint64)
         pad_o = np.zeros(nckf, dtype=np.uint32)
         pad_s[:st.shape[0]] = st
@@ -38,7 +39,8 @@ def build_container(kind, f, data, block, ckpt):
     index_off = 64
     ckoff_off = index_off + 8 * (nblocks + 1)
     ckstate_off = (ckoff_off + 4 * nblocks * nckf + 7) // 8 * 8
-    payload_off = (ckstate_off + 32 * nblocks * nckf + 15) // 16 * 16
+    hint_off = (ckstate_off + 32 * nblocks * nckf + 15) // 16 * 16
+    payload_off = hint_off + 32 * nblocks
     sizes = np.array([s.size for s in streams], dtype=np.uint64)
     boff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     payload = np.concatenate(streams)
@@ -50,5 +52,6 @@ def build_container(kind, f, data, block, ckpt):
     if nckf:
         out[ckoff_off:ckoff_off + 4 * nblocks * nckf] = np.concatenate(cko).view(np.uint8)
         out[ckstate_off:ckstate_off + 32 * nblocks * nckf] = np.concatenate(cks).reshape(-1).view(np.uint8)
+    out[hint_off:hint_off + 32 * nblocks] = np.concatenate(hints).view(np.uint8)
     out[payload_off:] = payload
     return out

@@ -74,6 +74,8 @@ def _load_oracle():
                                          C.c_void_p, C.POINTER(C.c_size_t)]
     lib.ans_oracle_pa_decode.restype = C.c_int
     lib.ans_oracle_pa_decode.argtypes = [C.c_int, C.c_uint32, _u8p, C.c_size_t, _u32p, C.c_size_t]
+    lib.ans_oracle_prelude_hints.restype = None
+    lib.ans_oracle_prelude_hints.argtypes = [_u8p, _u32p]
     lib.ans_oracle_bound.restype = C.c_size_t
     lib.ans_oracle_bound.argtypes = [C.c_int, C.c_uint32, C.c_size_t]
     return lib
@@ -143,6 +145,14 @@ def oracle_encode(kind, f, data, ckpt_interval=0):
     if nb == 0:
         raise RuntimeError("oracle encode failed")
     return out[:nb].copy(), info, st[: nck.value].copy(), off[: nck.value].copy()
+
+
+def prelude_hints(stream, prelude_offset):
+    """Container parse hints (8 x u32) of the codec prelude that starts at stream[prelude_offset]."""
+    buf = np.concatenate([np.ascontiguousarray(stream[prelude_offset:], dtype=np.uint8), np.zeros(16, dtype=np.uint8)])
+    h = np.zeros(8, dtype=np.uint32)
+    oracle().ans_oracle_prelude_hints(buf, h)
+    return h
 
 
 def oracle_decode(kind, f, stream, n, ref_f3_compat=False):

@@ -53,7 +53,7 @@ def test_layout_matches_python_container(oracle_built):
     c = cp.build_container(ol.FOLD, 1, data, 4096, 1024)
     h = adist.parse_header(torch.from_numpy(c))
     assert h["n"] == data.size and h["nblocks"] == 5 and h["ckpts_per_block"] == 3
-    assert adist.layout(h["nblocks"], h["ckpts_per_block"])[3] == h["payload_offset"]
+    assert adist.layout(h["nblocks"], h["ckpts_per_block"])[4] == h["payload_offset"]
     assert adist.pack_header(h) == c[:64].tobytes()
 
 

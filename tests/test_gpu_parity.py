@@ -613,21 +613,38 @@ def test_prelude_parser_paths(A, ctx):
                 for b in range(parts["header"].nblocks)]
     assert min(preludes) > 300, preludes
     assert parts["header"].max_nsyms + (1 << parts["header"].max_log2_frame) + 3 <= 65535  # fast kernel eligible
-    assert np.array_equal(codec.decode(cont, n), data)             # fast loop (default for small alphabets)
+    assert np.array_equal(codec.decode(cont, n), data)             # eight lanes per block on the parse hints (default)
     try:
-        for words in ("64", "32", "2"):                            # 256 / 128 / 8 staged bytes: fallback lanes of the fast loop
+        ctx.debug_set("ANSX_PARSE_FAST", "1")                      # one lane per block: the E-array fast loop ...
+        assert np.array_equal(codec.decode(cont, n), data)
+        for words in ("64", "32", "2"):                            # ... 256 / 128 / 8 staged bytes: its fallback lanes
             ctx.debug_set("ANSX_PARSE_STAGE_WORDS", words)
             assert np.array_equal(codec.decode(cont, n), data), words
         ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
-        ctx.debug_set("ANSX_PARSE_WIN", "1")                       # windowed parser
+        ctx.debug_set("ANSX_PARSE_FAST", None)
+        ctx.debug_set("ANSX_PARSE_WIN", "1")                       # one lane per block: windowed parser
         assert np.array_equal(codec.decode(cont, n), data)
         ctx.debug_set("ANSX_PARSE_WIN", None)
         ctx.debug_set("ANSX_PARSE_GENERIC", "1")                   # generic kernel
         assert np.array_equal(codec.decode(cont, n), data)
     finally:
         ctx.debug_set("ANSX_PARSE_STAGE_WORDS", None)
+        ctx.debug_set("ANSX_PARSE_FAST", None)
         ctx.debug_set("ANSX_PARSE_WIN", None)
         ctx.debug_set("ANSX_PARSE_GENERIC", None)
+    # the container's parse hints equal the oracle's (bit offsets of the top right subtrees of every prelude)
+    for b in range(parts["header"].nblocks):
+        want = ol.prelude_hints(parts["streams"][b], 0)
+        assert np.array_equal(parts["parse_hints"][b], want), b
+    # a corrupted hint must never fault (the result may be an error or wrong ints)
+    for word in (1, 3, 7):
+        bad = cont.copy()
+        hoff = parts["header"].payload_offset - 32 * parts["header"].nblocks
+        bad[hoff + 4 * word: hoff + 4 * word + 4] = np.frombuffer(np.uint32(0x7FFFFFF0).tobytes(), dtype=np.uint8)
+        try:
+            codec.decode(bad, n)
+        except A.AnsxError:
+            pass
     # preludes longer than one staged window (alphabets of thousands of symbols): the windowed parser
     # re-stages; cross-checked against the generic kernel
     wide = ol.gen_inputs("uniform24", n, seed=6)
@@ -635,11 +652,12 @@ def test_prelude_parser_paths(A, ctx):
         cw = codec_for(A, ctx, ol.FOLD, f, block_ints=16384, ckpt_interval=1024)
         contw = cw.encode(wide)
         assert np.array_equal(cw.decode(contw, n), wide), f
-        try:
-            ctx.debug_set("ANSX_PARSE_GENERIC", "1")
-            assert np.array_equal(cw.decode(contw, n), wide), f
-        finally:
-            ctx.debug_set("ANSX_PARSE_GENERIC", None)
+        for knob in ("ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN"):
+            try:
+                ctx.debug_set(knob, "1")
+                assert np.array_equal(cw.decode(contw, n), wide), (f, knob)
+            finally:
+                ctx.debug_set(knob, None)
 
 
 @pytest.mark.parametrize("f", [1, 3])

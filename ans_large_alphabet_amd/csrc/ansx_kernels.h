@@ -48,6 +48,8 @@ struct __attribute__((aligned(16))) ansx_enc_entry {
     double rcp;
 };
 
+typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
+
 enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
     // (words 4, 5 hold the 64-bit payload size)
     ANSX_G_NEAR = 6 };  // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
@@ -1200,7 +1202,11 @@ template <> struct enc_tab<false> {
     }
     typedef enc_ent entp;
     __device__ __forceinline__ enc_ent getp(const ansx_map& mp, u32 x, double, u32) const { return get(mp, x); }
-    __device__ __forceinline__ u32 fetchp(const ansx_map&, u32) const { return 0; }
+    __device__ __forceinline__ u32 fetchp(const ansx_map&, u32, u32& l) const
+    {
+        l = 0;
+        return 0;
+    }
     __device__ __forceinline__ enc_ent finishp(const ansx_map& mp, u32 x, u32, double, u32) const { return get(mp, x); }
     __device__ __forceinline__ void step_nb(enc_lane& L, u32 x, const enc_ent& e, const enc_quad_const&, u32 ql,
         u32 logM, __amdgpu_buffer_rsrc_t, u8* __restrict__ out) const
@@ -1211,7 +1217,12 @@ template <> struct enc_tab<false> {
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return L.st; }
 };
 template <> struct enc_tab<true> {
-    const u32* t;  // LDS
+    const u32* t;  // LDS (MODE 1) or the block's row of compact entries in HBM (MODE 2)
+    // MODE 2: the first `nhot` entries of the row are also held in LDS (hot[nhot] = 0 is a sentinel); the rest
+    // is read through a buffer descriptor over the wave's 16 rows, rowoff = this lane's row offset in bytes
+    const u32* hot;
+    u32 nhot, sent, rowoff;  // sent: index of the zero sentinel
+    ansx_u32x4 trs;
     typedef enc_ent_d ent;
     __device__ __forceinline__ enc_ent_d get(const ansx_map& mp, u32 x) const
     {
@@ -1252,13 +1263,21 @@ template <> struct enc_tab<true> {
         r.kpos = r.k << ql8;
         return r;
     }
-    // MODE 2 of k_encode: the table word comes from HBM through an inline-asm load (the caller owns
-    // the vmcnt wait), conversion happens one sub-batch later
-    __device__ __forceinline__ u32 fetchp(const ansx_map& mp, u32 x) const
+    // MODE 2 of k_encode: alphabets too large for 16 LDS tables per wave.  A skewed list spends most of its
+    // steps on the first few hundred symbols: those entries sit in LDS, the others come from HBM / L2
+    // through an inline-asm buffer load whose offset is out of range for the hot lanes (no request leaves
+    // the CU for them, the load returns 0; with every lane going to L2 the 1024 waves issued ~150 requests per
+    // clock, more than its channels take).  The word is hot | cold (one of them is 0); the caller owns the
+    // vmcnt wait of the cold part, conversion happens one sub-batch later.
+    __device__ __forceinline__ u32 fetchp(const ansx_map& mp, u32 x, u32& l) const
     {
         const u32 k = map_nbytes(mp, x);
+        const u32 sym = map_sym(mp, x, k);
+        const bool is_hot = sym < nhot;
+        l = hot[is_hot ? sym : sent];
+        const u32 voff = is_hot ? ANSX_BUF_OOB : rowoff + 4 * sym;
         u32 e;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(e) : "v"(t + map_sym(mp, x, k)) : "memory");
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(e) : "v"(voff), "s"(trs) : "memory");
         return e;
     }
     __device__ __forceinline__ enc_ent_n finishp(const ansx_map& mp, u32 x, u32 e, double Md, u32 ql8) const
@@ -1283,6 +1302,7 @@ template <> struct enc_tab<true> {
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return f64_to_u64_exact(L.sd); }
 };
 
+#define ANSX_ENC_HOT 577  // MODE 2: LDS row = 576 hot entries + sentinel (odd stride; 16 rows = 36.9 KB per wave)
 #define ANSX_ENC_U 8    // table entries per lane fetched ahead
 #define ANSX_ENC_XB 32  // inputs per lane fetched ahead (one super-batch)
 
@@ -1302,16 +1322,19 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     const u32 b = gt >> 2, ql = gt & 3;
     constexpr bool LDS_TABLE = MODE == 1;
     constexpr bool F64 = MODE != 0;
-    if (LDS_TABLE) {
-        // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries)
+    if (LDS_TABLE || MODE == 2) {
+        // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries): all of a table
+        // (MODE 1) or its first lds_stride - 1 entries plus a zero sentinel (MODE 2)
         const u32 b0 = blockIdx.x * 16;
+        const u32 take = MODE == 2 ? lds_stride - 1 : lds_stride;
         for (u32 j = 0; j < 16; j++) {
             const u32 bj = b0 + j;
             if (bj >= g.nblocks) break;
             u32 nsj = blk[bj].max_sym + 1;
-            nsj = nsj < lds_stride ? nsj : lds_stride;  // (a block beyond the hint-sized LDS carries a status and is skipped)
+            nsj = nsj < take ? nsj : take;  // (a block beyond the hint-sized LDS carries a status and is skipped)
             const u32* src32 = tab32 + (u64)bj * NSP;
             for (u32 s = threadIdx.x; s < nsj; s += 64) lds_tab[j * lds_stride + s] = src32[s];
+            if (MODE == 2 && threadIdx.x == 0) lds_tab[j * lds_stride + take] = 0;
         }
         __syncthreads();
     }
@@ -1325,8 +1348,16 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     const u32* src = in + (u64)b * g.block_ints;
     enc_tab<F64> tab;
     if constexpr (MODE == 1) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
-    else if constexpr (MODE == 2) tab.t = tab32 + (u64)b * NSP;
-    else tab.t = table + (u64)b * NSP;
+    else if constexpr (MODE == 2) {
+        tab.t = tab32 + (u64)b * NSP;
+        tab.hot = lds_tab + (threadIdx.x >> 2) * lds_stride;
+        const u32 own = B->max_sym + 1;
+        tab.nhot = own < lds_stride - 1 ? own : lds_stride - 1;  // entries of THIS block that were staged
+        tab.sent = lds_stride - 1;
+        tab.rowoff = (threadIdx.x >> 2) * NSP * 4;
+        const u64 ba = (u64)(uintptr_t)(tab32 + (u64)(blockIdx.x * 16) * NSP);
+        tab.trs = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, 16u * NSP * 4u, 0x00020000u };
+    } else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
     // buffer view of the wave's 16 scratch slots (the host guarantees 16 * scr_stride < 2^31 for
     // the LDS variant): wave-uniform descriptor, per-lane 32-bit offsets
@@ -1389,10 +1420,10 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         u32 xa[ANSX_ENC_XB], xb[ANSX_ENC_XB];
 #pragma unroll
         for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = base[4 * (gi - 1 - j)];
-        u32 raw1[ANSX_ENC_U] = {};
+        u32 raw1[ANSX_ENC_U] = {}, raw1l[ANSX_ENC_U] = {};
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j]);
+            for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j], raw1l[j]);
         }
         while (gi) {
             const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
@@ -1434,10 +1465,10 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                                  "+v"(raw1[5]), "+v"(raw1[6]), "+v"(raw1[7]));
 #pragma unroll
                     for (int j = 0; j < ANSX_ENC_U; j++)
-                        e0[j] = tab.finishp(f, xa[sb * ANSX_ENC_U + j], raw1[j], Md, 8 * ql);
+                        e0[j] = tab.finishp(f, xa[sb * ANSX_ENC_U + j], raw1[j] | raw1l[j], Md, 8 * ql);
                     if (sb + 1 < ANSX_ENC_XB / ANSX_ENC_U) {
 #pragma unroll
-                        for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[(sb + 1) * ANSX_ENC_U + j]);
+                        for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[(sb + 1) * ANSX_ENC_U + j], raw1l[j]);
                     }
                 } else {
 #pragma unroll
@@ -1478,7 +1509,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
             if constexpr (MODE == 2) {
                 if (gi) {
 #pragma unroll
-                    for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j]);
+                    for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j], raw1l[j]);
                 }
             }
         }
@@ -2304,7 +2335,6 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
 // younger, so the wait never touches them (letting the compiler wait for these loads costs a
 // drain of the output stores per refill -- the reason an earlier ring attempt was slower than
 // whole-stream staging).  Used when every segment of the block has the same length.
-typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
 struct dec_ring_desc {
     ansx_u32x4 rsrc;  // buffer descriptor over [stream - backoff, stream + sbytes + slack) inside the container
     int backoff;      // stream offset s is at buffer offset s + backoff
@@ -2454,56 +2484,62 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
     if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
     __syncthreads();
-    // wave 0: frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1),
-    // compaction of the present symbols, running base, start-of-symbol bitmap
-    if (tid < 64) {
+    // Frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1), compaction of the
+    // present symbols, running base, start-of-symbol bitmap -- by the whole workgroup, nt symbols per round:
+    // one packed exclusive scan (frequency in the low word, presence in the high word) gives every present
+    // symbol its base and its rank.  The inc[] values of four rounds are requested together, so a block
+    // pays one global round trip per 4 nt symbols (one wave doing 64 symbols per round with the loads
+    // inside the round was most of this kernel's time on 2300-symbol alphabets).
+    {
+        __shared__ u64 sh_scan[8];
         const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
-        u32 carryF = 0, carryP = 0, bad = 0;
-        for (u32 s0 = 0; s0 < ns; s0 += 64) {
-            const u32 s = s0 + tid;
-            u32 fr = 0;
-            if (s < ns) {
-                const u32 cur = gc[s + 1];
-                const u32 prv = s ? gc[s] + 1u : 0u;
-                fr = cur - prv;
-                if (cur < prv || fr > M || fr > 0xFFFFu) {  // entries hold 16-bit freq and base
-                    bad = 1;
-                    fr = 0;
-                }
-            }
-            const u32 pres = fr ? 1u : 0u;
-            u32 incF = fr, incP = pres;
+        u64 carry = 0;
+        u32 bad = 0;
+        for (u32 c0 = 0; c0 < ns; c0 += 4 * nt) {
+            u32 cur4[4], prv4[4];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 tF = __shfl_up(incF, d), tP = __shfl_up(incP, d);
-                if ((int)tid >= d) {
-                    incF += tF;
-                    incP += tP;
+            for (u32 q = 0; q < 4; q++) {
+                const u32 s = c0 + q * nt + tid;
+                cur4[q] = s < ns ? gc[s + 1] : 0u;
+                prv4[q] = (s < ns && s) ? gc[s] + 1u : 0u;
+            }
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                const u32 s = c0 + q * nt + tid;
+                if (c0 + q * nt >= ns) break;  // uniform
+                u32 fr = 0;
+                if (s < ns) {
+                    fr = cur4[q] - prv4[q];
+                    if (cur4[q] < prv4[q] || fr > M || fr > 0xFFFFu) {  // entries hold 16-bit freq and base
+                        bad = 1;
+                        fr = 0;
+                    }
+                }
+                const u64 packed = (u64)fr | ((u64)(fr ? 1u : 0u) << 32);
+                u64 total;
+                const u64 ex = carry + block_excl_scan<u64>(packed, sh_scan, tid, nt, &total);
+                carry += total;
+                if (fr) {
+                    const u64 base64 = ex & 0xFFFFFFFFull;
+                    const u32 r = (u32)(ex >> 32);
+                    if (base64 < M && base64 + fr <= M) {  // (then r <= base < M and r <= s < max_ns)
+                        const u32 base = (u32)base64;
+                        // ANSrfold: the most-frequent values follow the 4-byte flag word
+                        // (ans_reorder_fold.hpp:132-154)
+                        u32 mfv = 0;
+                        if (RFOLD && rflag && s < T) mfv = ld_u32_unaligned(stream + 4 + 4 * (u64)s);
+                        ep[r] = make_uint2((base << 16) | fr, dec_make_pv(f, s, RFOLD && rflag, T, mfv));
+                        atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
+                    } else {
+                        bad = 1;
+                    }
                 }
             }
-            const u32 base = carryF + incF - fr;
-            if (pres) {
-                if (base < M && base + fr <= M) {
-                    const u32 r = carryP + incP - 1;
-                    // ANSrfold: the most-frequent values follow the 4-byte flag word
-                    // (ans_reorder_fold.hpp:132-154)
-                    u32 mfv = 0;
-                    if (RFOLD && rflag && s < T) mfv = ld_u32_unaligned(stream + 4 + 4 * (u64)s);
-                    ep[r] = make_uint2((base << 16) | fr, dec_make_pv(f, s, RFOLD && rflag, T, mfv));
-                    atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
-                } else {
-                    bad = 1;
-                }
-            }
-            carryF += __shfl(incF, 63);
-            carryP += __shfl(incP, 63);
         }
-        if (carryF != M) bad = 1;
-        if (__ballot(bad != 0) != 0) {
-            if (tid == 0) {
-                sh_bad = 1;
-                atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
-            }
+        if ((carry & 0xFFFFFFFFull) != M || (carry >> 32) > max_ns) bad = 1;
+        if (bad) {
+            sh_bad = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
         }
     }
     __syncthreads();

@@ -582,12 +582,6 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (getenv("ANSX_DBG_TIMES")) {
-        u64 tt[16];
-        (void)hipMemcpy(tt, (u8*)c->misc.p + 64, sizeof(tt), hipMemcpyDeviceToHost);
-        fprintf(stderr, "phases(10ns ticks): hist %lld reduce %lld sortH %lld P4 %lld P5a %lld P5b %lld sat %lld XH %lld P7 %lld table %lld prelude %lld\n",
-            (long long)(tt[1]-tt[0]),(long long)(tt[2]-tt[1]),(long long)(tt[3]-tt[2]),(long long)(tt[4]-tt[3]),(long long)(tt[5]-tt[4]),(long long)(tt[6]-tt[5]),(long long)(tt[7]-tt[6]),(long long)(tt[8]-tt[7]),(long long)(tt[9]-tt[8]),(long long)(tt[10]-tt[9]),(long long)(tt[11]-tt[10]));
-    }
     const u32 fl = c->h_pin[ANSX_G_ERR];
     if (fl & (1u << 6)) return ANSX_ERR_DOMAIN;
     if (fl & (1u << ANSX_G_VIOL_BIT)) return ANSX_RETRY_GENERAL;

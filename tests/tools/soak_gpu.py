@@ -29,7 +29,7 @@ def gen(kind, n):
     if c == 7: return rng.geometric(0.001, size=n).astype(np.uint32)
     return ol.gen_inputs("zipf20s1.2", n, seed=int(rng.integers(1, 1 << 30)))
 blocks = [(16384, 1024), (16384, 256), (4096, 512), (65536, 1024), (8192, 2048), (16448, 1028), (1024, 64), (32768, 4096), (2052, 4), (16384, 16384)]
-t0 = time.time(); it = 0; fails = 0
+t0 = time.time(); it = 0; fails = 0; near = 0
 while time.time() - t0 < budget:
     it += 1
     kind, f = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0)][int(rng.integers(0, 7))]
@@ -41,6 +41,7 @@ while time.time() - t0 < budget:
     codec = A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt) if kind == ol.MSB else cls(f, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
     try:
         cont = codec.encode(data)
+        near += ctx.last_encode_stats()["near_threshold_decisions"]
         out = codec.decode(cont, n)
         ok = np.array_equal(out, data)
         if ok and n <= 300000 and it % 3 == 0:   # oracle parity of every block stream (CPU cost)
@@ -56,4 +57,8 @@ while time.time() - t0 < budget:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         np.save(os.path.join(ROOT, "gpurun_out", "soak_fail_%d.npy" % it), data)
     if it % 50 == 0: print("it", it, "elapsed %.0f s" % (time.time() - t0), "fails", fails); sys.stdout.flush()
-print("SOAK done: iterations", it, "fails", fails)
+# frame-size decisions within 1e-12 (relative) of the 1.001 H threshold: the only place where the portable log2
+# could in principle decide differently from glibc's; expected 0
+print("SOAK done: iterations", it, "fails", fails, "near_threshold_decisions", near)
+assert near == 0, "near-threshold frame-size decisions seen: compare those blocks with the reference"
+sys.exit(1 if fails else 0)

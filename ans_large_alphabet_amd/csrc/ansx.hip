@@ -211,6 +211,12 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     return ANSX_OK;
 }
 
+// fold maps have power-of-two thresholds 2^(f+7), 2^(f+15), 2^(f+23): the encoder derives the exception-byte
+// count from the bit length instead of three comparisons
+bool map_is_pow2(const ansx_map& m)
+{
+    return m.t1 >= 2 && (m.t1 & (m.t1 - 1)) == 0 && m.t1 < (1u << 15) && m.t2 == m.t1 << 8 && m.t3 == m.t1 << 16;
+}
 int flags_to_status(u32 fl)
 {
     if (fl & (1u << 6)) return ANSX_ERR_DOMAIN;
@@ -431,9 +437,14 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // 31-bit offsets)
     const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull && !test_fixup;
     if (f64_ok && enc_lds <= 40 * 1024) {
-        LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
-            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off);
+        if (map_is_pow2(g.map))
+            LAUNCH(c, "k_encode", (k_encode<1, true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off);
+        else
+            LAUNCH(c, "k_encode", (k_encode<1, false>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off);
     } else if (f64_ok && !c->dbg.encode_gtab16) {
         // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
         LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, (size_t)16 * ANSX_ENC_HOT * 4, s, src, g, NSP,
@@ -567,9 +578,14 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     const u32 lds_stride = ns_cap | 1u;  // odd stride spreads the 16 tables over the banks
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
     if (enc_lds <= 40 * 1024) {
-        LAUNCH(c, "k_encode", (k_encode<1>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
-            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off);
+        if (map_is_pow2(g.map))
+            LAUNCH(c, "k_encode", (k_encode<1, true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off);
+        else
+            LAUNCH(c, "k_encode", (k_encode<1, false>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off);
     } else {
         LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, (size_t)16 * ANSX_ENC_HOT * 4, s, src, g, NSP,
             (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,

@@ -1302,6 +1302,43 @@ template <> struct enc_tab<true> {
     __device__ __forceinline__ u64 state(const enc_lane& L) const { return f64_to_u64_exact(L.sd); }
 };
 
+
+// ---- explicitly scheduled main loop of the LDS-table encoder (MODE 1) ---------------------------------
+// One wave per SIMD runs alone (64 Ki chains = 1024 waves), so its own instruction stream is all that fills the
+// SIMD.  The step is written out operation by operation -- state chain (8 dependent f64 operations: compare,
+// select, ldexp, trunc, mul, trunc, fma with clamp, fma), byte emission, the table-entry arithmetic of the
+// NEXT symbol (B) and the fold map + LDS reads of the symbol three steps ahead (A) -- with a scheduling barrier
+// after each line, 44 VALU instructions per symbol (58.8 before).  What was measured on the way
+// (tests/tools/ubench_valu.hip, in-kernel s_memtime traces):
+//  * a lone wave issues one VALU instruction per ~4.6 cycles; 8.4 / 6.1 / 5.5 if a source was written 1 / 2 / 3
+//    instructions earlier;
+//  * replayed from registers, this step costs 210 cycles (254 with its LDS reads and stores); inside the kernel
+//    it averages ~350: a third of the steps stall 400-1200 cycles on the vector-memory path (4 scattered
+//    operations per step and wave, 16 cache lines each, one address unit per CU) -- the order of the VALU work
+//    changes nothing measurable, the placement of the loads does (bursts of 8 neighbouring loads: -5 %).
+struct encp_a {   // after stage A: exception bytes k, 8k, and the two halves of the table word (LDS reads in flight)
+    u32 k, sh, F16, B16;
+};
+struct encp_e {   // after stage B
+    double Fd, rcp, MF, based, omF;  // freq, 1/freq (under-estimate), M - freq, base, 1 - freq
+    u32 thr_hi, k, sh;               // high word of 2^36 * freq; exception bytes k; 8k
+    u32 off1, off2;                  // buffer-offset deltas of the byte / short store: 0 / k & 1, or out of range
+};
+#define ANSX_SLOT() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ u32 f64_hi(double d) { return (u32)(__builtin_bit_cast(u64, d) >> 32); }
+__device__ __forceinline__ u32 f64_lo(double d) { return (u32)__builtin_bit_cast(u64, d); }
+__device__ __forceinline__ u32 ffbh_u32(u32 x)  // leading zeros; 0xFFFFFFFF for 0 (__builtin_clz(0) is undefined)
+{
+    u32 r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ u32 quad_add_dpp(u32 v)
+{
+    // v + v[quad_perm]: the DPP-combine pass folds the move into the add; hazards are the compiler's
+    return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
 #define ANSX_ENC_HOT 577  // MODE 2: LDS row = 576 hot entries + sentinel (odd stride; 16 rows = 36.9 KB per wave)
 #define ANSX_ENC_U 8    // table entries per lane fetched ahead
 #define ANSX_ENC_XB 32  // inputs per lane fetched ahead (one super-batch)
@@ -1311,7 +1348,7 @@ template <> struct enc_tab<true> {
 // MODE 2: compact tables in HBM (alphabets too large for LDS), otherwise as MODE 1: the entries of
 //         the next sub-batch are fetched with inline-asm loads and consumed behind exact vmcnt
 //         waits (24 = the stores of one sub-batch, 32 = the input prefetch of a super-batch)
-template <int MODE>
+template <int MODE, bool POW2 = false>
 __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
@@ -1323,18 +1360,38 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     constexpr bool LDS_TABLE = MODE == 1;
     constexpr bool F64 = MODE != 0;
     if (LDS_TABLE || MODE == 2) {
-        // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries): all of a table
-        // (MODE 1) or its first lds_stride - 1 entries plus a zero sentinel (MODE 2)
+        // the wave stages the compact tables of its 16 blocks (coalesced 4-byte entries): a whole row of
+        // lds_stride entries (MODE 1; what lies beyond a block's own alphabet is never looked up) or the first
+        // lds_stride - 1 entries plus a zero sentinel (MODE 2).  Two rows per round, every load of a round in
+        // flight before the first LDS write (row by row behind a dependent load of the alphabet size this took
+        // 90 k cycles, 6 % of the kernel).
         const u32 b0 = blockIdx.x * 16;
         const u32 take = MODE == 2 ? lds_stride - 1 : lds_stride;
-        for (u32 j = 0; j < 16; j++) {
-            const u32 bj = b0 + j;
-            if (bj >= g.nblocks) break;
-            u32 nsj = blk[bj].max_sym + 1;
-            nsj = nsj < take ? nsj : take;  // (a block beyond the hint-sized LDS carries a status and is skipped)
-            const u32* src32 = tab32 + (u64)bj * NSP;
-            for (u32 s = threadIdx.x; s < nsj; s += 64) lds_tab[j * lds_stride + s] = src32[s];
-            if (MODE == 2 && threadIdx.x == 0) lds_tab[j * lds_stride + take] = 0;
+        const u32 lim = take < NSP ? take : NSP;
+        for (u32 j = 0; j < 16; j += 2) {
+            if (b0 + j >= g.nblocks) break;
+            const bool two = b0 + j + 1 < g.nblocks;
+            const u32* r0 = tab32 + (u64)(b0 + j) * NSP;
+            const u32* r1 = r0 + (two ? NSP : 0);
+            u32 v0[10], v1[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const u32 e = threadIdx.x + 64 * i;
+                v0[i] = e < lim ? r0[e] : 0u;
+                v1[i] = e < lim ? r1[e] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const u32 e = threadIdx.x + 64 * i;
+                if (e < take) {
+                    lds_tab[j * lds_stride + e] = v0[i];
+                    if (two) lds_tab[(j + 1) * lds_stride + e] = v1[i];
+                }
+            }
+            if (MODE == 2 && threadIdx.x == 0) {
+                lds_tab[j * lds_stride + take] = 0;
+                if (two) lds_tab[(j + 1) * lds_stride + take] = 0;
+            }
         }
         __syncthreads();
     }
@@ -1417,6 +1474,202 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
             pbias = obase;
             L.p += obase;
         }
+        bool piped = false;
+        if constexpr (MODE == 1) {
+            if (ck_per_batch) {
+                piped = true;
+                // Inputs come through a buffer view of the wave's 16 blocks, one load per step straight into the
+                // registers a sub-batch of 8 steps just released: they are first read 21 steps (>= 84 vector-memory
+                // operations) later.  vmcnt counts at most
+                // 63 operations in flight, so anything with more than 63 younger operations has completed: no
+                // wait is needed (and none could name it).  A lane whose block has no further group computes a
+                // negative offset, i.e. one beyond num_records: the load returns 0, whose table lookups are harmless.
+                const u64 iba = (u64)(uintptr_t)(in + (u64)(blockIdx.x * 16) * g.block_ints);
+                const u64 irem = g.n - (u64)(blockIdx.x * 16) * g.block_ints;
+                const u32 inrec = (u32)((irem < 16ull * g.block_ints ? irem : 16ull * g.block_ints) * 4);
+                const ansx_u32x4 irs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)iba),
+                    (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(inrec), 0x00020000u };
+                // byte offset of group (gi - 32), this lane's state, in that view
+                u32 vcur = (threadIdx.x >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (gi - ANSX_ENC_XB);
+                u32 xa[ANSX_ENC_XB];
+#define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
+#pragma unroll
+                for (int j = 0; j < ANSX_ENC_XB; j++) ANSX_XLOAD(xa[j], vcur, j);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < ANSX_ENC_XB; i += 8)
+                    asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
+                                 "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
+                // the quad's table as 16-bit halves (freq, base), read with two ds_read_u16: no unpacking on the
+                // VALU.  Issued as inline asm: the halves are consumed two steps later behind ONE hand-counted wait.
+                const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)lds_tab + 4 * (threadIdx.x >> 2) * lds_stride;
+                const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
+                // stage A: value -> (k, symbol), the two halves of its table word requested from LDS
+                auto stage_a = [&](u32 x) {
+                    encp_a a;
+                    if constexpr (POW2) {
+                        const u32 d = __builtin_elementwise_sub_sat(c32f, ffbh_u32(x));
+                        a.k = d >> 3;
+                        a.sh = d & 0x18u;
+                    } else {
+                        a.k = map_nbytes(f, x);
+                        a.sh = a.k << 3;
+                    }
+                    const u32 la = tbase + 4 * (__umul24(a.k, f.D) + (x >> a.sh));
+                    asm volatile("ds_read_u16 %0, %1" : "=v"(a.F16) : "v"(la) : "memory");
+                    asm volatile("ds_read_u16 %0, %1 offset:2" : "=v"(a.B16) : "v"(la) : "memory");
+                    return a;
+                };
+                // stage B: the arithmetic form of a table entry (see enc_tab<true>::getp for the reciprocal)
+                auto stage_b = [&](const encp_a& a) {
+                    encp_e e;
+                    e.Fd = (double)a.F16;
+                    e.based = (double)a.B16;
+                    const double r0 = __builtin_amdgcn_rcp(e.Fd);
+                    e.rcp = __builtin_fma(__builtin_fma(-e.Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
+                    e.thr_hi = f64_hi(e.Fd) + (36u << 20);  // 2^36 * freq: same mantissa, low word 0
+                    e.MF = Md - e.Fd;
+                    e.omF = 1.0 - e.Fd;
+                    e.k = a.k;
+                    e.sh = a.sh;
+                    e.off1 = (a.k << 31) + ANSX_BUF_OOB;
+                    e.off2 = (a.k - 2u) & 0x80000001u;
+                    return e;
+                };
+                encp_a a0 = stage_a(xa[0]);
+                encp_a an = stage_a(xa[1]);   // consumed by stage B one step ahead of its symbol ...
+                encp_a an2 = stage_a(xa[2]);  // ... two steps after its LDS reads were issued
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0.F16), "+v"(a0.B16) : : "memory");
+                encp_e ec = stage_b(a0);
+                double sd = L.sd;
+                u32 pcur = L.p;
+                while (gi) {
+                    const u32 top = gi;
+                    const u32 vnext = vcur - 16 * ANSX_ENC_XB;
+#pragma unroll
+                    for (int j = 0; j < ANSX_ENC_XB; j++) {
+                        if (j % ANSX_ENC_U == 0) {
+                            // the eight registers the previous sub-batch released take the inputs of their steps in
+                            // the next super-batch (the last eight of THIS one when requested at step 0): eight
+                            // neighbouring loads share their cache lines
+#pragma unroll
+                            for (int i = 0; i < ANSX_ENC_U; i++) {
+                                const int e = (j + ANSX_ENC_XB - ANSX_ENC_U + i) % ANSX_ENC_XB;
+                                if (j == 0) ANSX_XLOAD(xa[e], vcur, e);
+                                else ANSX_XLOAD(xa[e], vnext, e);
+                            }
+                        }
+                        const u32 x = xa[j];
+                        const u32 x2 = xa[(j + 3) % ANSX_ENC_XB];
+                        // One operation per line, a scheduling barrier after each: the order written is the order
+                        // issued.  A lone wave issues an instruction every ~4.6 cycles if none of its sources was
+                        // written by one of the THREE instructions before it; otherwise it loses a slot
+                        // (tests/tools/ubench_valu.hip: 8.4 / 6.1 / 5.5 / 4.6 cycles per operation at dependency
+                        // distance 1 / 2 / 3 / 4).  Four strands are therefore rotated, one operation each per
+                        // row, so that consecutive operations of a strand are four slots apart:
+                        //   [C] the state chain of this symbol      [E] its byte emission
+                        //   [B] the table entry of the next symbol  [A] map + LDS reads of the symbol 3 steps ahead
+                        encp_a a2;
+                        encp_e en;
+                        const u32 k = ec.k;
+#define Q ANSX_SLOT();
+                        // row 0.  The halves of `an` were requested two steps ago; the only younger LDS
+                        // operations are the two of `an2`.
+                        Q asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(an.F16), "+v"(an.B16) : : "memory");
+                        Q const bool rn = f64_hi(sd) >= ec.thr_hi;                                        // C1 renormalise?
+                        Q const u32 w = f64_lo(sd + 4503599627370496.0);                                   // E  low word of the state (< 2^52)
+                        Q en.Fd = (double)an.F16;                                                          // B
+                        Q u32 lz2 = 0, d2 = 0;
+                        if constexpr (POW2) lz2 = ffbh_u32(x2);                                            // A  (-1 for 0)
+                        else a2.k = map_nbytes(f, x2);
+                        // row 1
+                        Q int ex = rn ? -32 : 0;                                                           // C2
+                        asm("" : "+v"(ex));  // (keeps ldexp(sd, select) from becoming select(ldexp, sd): 3 operations)
+                        Q const u32 fp = rn ? qc.four_pos : 0u;                                            // E
+                        Q const double r0 = __builtin_amdgcn_rcp(en.Fd);                                   // B
+                        Q if constexpr (POW2) d2 = __builtin_elementwise_sub_sat(c32f, lz2);               // A  8k + (0..7)
+                        // row 2
+                        Q const double t = __builtin_ldexp(sd, ex);                                        // C3
+                        Q const u32 v = (k << (8 * ql)) + fp;                                              // E  packed byte counts
+                        Q en.based = (double)an.B16;                                                       // B
+                        Q if constexpr (POW2) a2.k = d2 >> 3;                                              // A
+                        // row 3
+                        Q const double s0 = __builtin_trunc(t);                                            // C4 state after renormalisation
+                        Q const u32 s1 = quad_add_dpp<0xB1>(v);                                            // E
+                        Q const double nt = __builtin_fma(-en.Fd, r0, 1.0 - 1.8189894035458565e-12);      // B
+                        Q if constexpr (POW2) a2.sh = d2 & 0x18u;                                          // A
+                        else a2.sh = a2.k << 3;
+                        // row 4
+                        Q double q = s0 * ec.rcp;                                                          // C5
+                        Q const u32 S = quad_add_dpp<0x4E>(s1);                                            // E  the quad's counts, a byte per lane
+                        Q const double sb = s0 + ec.based;                                                 // C
+                        Q const u32 xs2 = x2 >> a2.sh;                                                     // A
+                        // row 5
+                        Q q = __builtin_trunc(q);                                                          // C6 quotient or quotient - 1
+                        Q const double u = s0 + ec.omF;                                                    // C
+                        Q en.rcp = __builtin_fma(nt, r0, r0);                                              // B
+                        Q const u32 sym2 = __umul24(a2.k, f.D) + xs2;                                      // A
+                        // row 6
+                        Q const double base2 = __builtin_fma(q, ec.MF, sb);                                // C
+                        Q const u32 m = S & qc.lomask;                                                     // E
+                        Q const u32 pnext = __builtin_amdgcn_sad_u8(S, 0u, pcur);                          // E  cursor after this step
+                        Q const u32 la2 = tbase + 4 * sym2;                                                // A
+                        // row 7
+                        Q const double one_short = __builtin_fmin(__builtin_fmax(__builtin_fma(-q, ec.Fd, u), 0.0), 1.0);  // C7
+                        Q const u32 a = __builtin_amdgcn_sad_u8(m, 0u, pcur);                              // E  this lane's bytes start here
+                        Q en.thr_hi = f64_hi(en.Fd) + (36u << 20);                                         // B
+                        Q const u32 t8 = ec.sh & 8u;                                                       // E  8 (k & 1)
+                        // row 8
+                        Q sd = __builtin_fma(one_short, ec.MF, base2);                                     // C8 new state
+                        Q en.MF = Md - en.Fd;                                                              // B
+                        Q en.k = an.k;
+                        en.sh = an.sh;
+                        const u32 km2 = an.k - 2u;                                                         // B
+                        Q asm volatile("ds_read_u16 %0, %1" : "=v"(a2.F16) : "v"(la2) : "memory");        // A
+                        // row 9
+                        Q const u32 addr1 = a + ec.off1;                                                   // E
+                        Q const u32 addr2 = a + ec.off2;                                                   // E
+                        Q en.omF = 1.0 - en.Fd;                                                            // B
+                        Q asm volatile("ds_read_u16 %0, %1 offset:2" : "=v"(a2.B16) : "v"(la2) : "memory");  // A
+                        // row 10
+                        Q const u32 ak = a + k;                                                            // E
+                        Q const u32 xv = x >> t8;                                                          // E
+                        Q en.off1 = (an.k << 31) + ANSX_BUF_OOB;                                           // B  0 when k is odd
+                        Q en.off2 = km2 & 0x80000001u;                                                     // B  k & 1 when k >= 2
+                        // row 11
+                        Q __builtin_amdgcn_raw_buffer_store_b8((u8)x, rsrc, addr1, 0, 0);                  // E  k odd: byte 0
+                        Q const u32 addr3 = rn ? ak : ANSX_BUF_OOB;                                        // E
+                        Q pcur = pnext;
+                        Q __builtin_amdgcn_raw_buffer_store_b16((u16)xv, rsrc, addr2, 0, 0);               // E  k >= 2: the two high bytes
+                        // row 12
+                        Q __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, addr3, 0, 0);                     // E  renormalisation word
+                        Q;
+#undef Q
+                        ec = en;
+                        an = an2;
+                        an2 = a2;
+                        if (j % ANSX_ENC_U == ANSX_ENC_U - 1) {
+                            L.sd = sd;
+                            L.p = pcur;
+                            record(top - (u32)(j + 1));
+                        }
+                    }
+                    gi = top - ANSX_ENC_XB;
+                    vcur = vnext;
+                }
+                // nothing may still be on its way into a register when the loop is left
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < ANSX_ENC_XB; i += 8)
+                    asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
+                                 "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
+                asm volatile("" : "+v"(an.F16), "+v"(an.B16), "+v"(an2.F16), "+v"(an2.B16));
+#undef ANSX_XLOAD
+                L.sd = sd;
+                L.p = pcur;
+            }
+        }
+        if (!piped) {
         u32 xa[ANSX_ENC_XB], xb[ANSX_ENC_XB];
 #pragma unroll
         for (int j = 0; j < ANSX_ENC_XB; j++) xa[j] = base[4 * (gi - 1 - j)];
@@ -1513,6 +1766,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                 }
             }
         }
+        }  // !piped
         L.p -= pbias;
         pbias = 0;
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick bench summary: scripts/quick.sh <tag> [bench args]
 O=gpurun_out/q; mkdir -p $O; tag=$1; shift
-python bench.py --steps 10 --warmup 2 --no-cpu "$@" > $O/$tag.json 2> $O/$tag.err || { tail -5 $O/$tag.err; exit 1; }
+python bench.py --steps 10 --warmup 2 --no-cpu "$@" > $O/$tag.json 2> $O/$tag.err || { tail -2 $O/$tag.err; [ -s $O/$tag.json ] || exit 1; }
 grep -v "amdgpu.ids" $O/$tag.err | tail -3
 python - $O/$tag.json <<'PY'
 import json,sys

@@ -1,0 +1,33 @@
+#!/bin/bash
+# one-off SQ counter probe: scripts/sqprobe.sh <tag> [bench args]
+TAG=${1:-probe}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+python3 -c 'import torch; torch.zeros(1).cuda()' 2>/dev/null
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
+           "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
+           "SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+           "SQ_WAVES SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" \
+           "SQ_WAVES SQ_IFETCH SQ_IFETCH_LEVEL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU" \
+           "SQ_WAVES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_INSTS SQ_ACTIVE_INST_VALU2"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/sq$i -- \
+      python3 bench.py --steps 1 --warmup 0 --no-cpu --no-profile --no-extra "$@" > /dev/null 2> $OUT/sq$i.err || echo "SQ set $i failed"
+done
+python3 - $OUT <<'PY'
+import sys,glob,csv,collections
+out=sys.argv[1]
+acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(out+'/sq*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name'].split('(')[0]
+        if 'k_encode' not in k and 'k_decode' not in k: continue
+        acc[k][r['Counter_Name']]+=float(r['Counter_Value']); cnt[k][r['Counter_Name']]+=1
+for k in acc:
+    w=acc[k].get('SQ_WAVES',1)/max(1,cnt[k].get('SQ_WAVES',1))
+    print(k, 'waves/launch', w)
+    for c in sorted(acc[k]):
+        if c=='SQ_WAVES': continue
+        v=acc[k][c]/cnt[k][c]
+        print('   %-32s %14.1f per launch  %12.1f per wave'%(c, v, v/w))
+PY

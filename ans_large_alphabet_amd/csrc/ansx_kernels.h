@@ -2373,7 +2373,9 @@ __global__ __launch_bounds__(64) void k_parse_prelude_par(const u8* __restrict__
 // words + v_alignbyte) or straight from global memory (one unaligned 8-byte load)
 // per-quad stream ring of the block decoder: ANSX_RING_CHK steps per refill check, 32 bytes per lane
 // and step of check interval per refill (>= the 28 bytes a quad can consume per step)
+#ifndef ANSX_RING_CHK
 #define ANSX_RING_CHK 4
+#endif
 #define ANSX_RING_BYTES (128 * ANSX_RING_CHK)
 template <int MODE>
 __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end)

@@ -239,11 +239,13 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         return;
     }
     if (tid == 0 && (u64)vmax + T >= (1u << 30)) atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
-    // Thresholds by radix selection over LDS histograms (no sorting, no bisection):
-    //   c*  = largest c with #values(count >= c) >= T        (2 levels of 7 bits, counts <= 16384)
-    //   v*  = K-th smallest value among those with count == c* (3 levels of 10 bits, values < 2^30)
-    // One table pass per level; lanes of wave 0 locate the bucket where the running total
-    // crosses the target.
+    // Thresholds (no sorting of the block, no bisection):
+    //   c*  = largest c with #values(count >= c) >= T.  T values of count >= c* exist, so c* <= nb / T (<= 64):
+    //         one table pass over a histogram of min(count, CAPC).  Counts 1..4 -- nearly every slot of a skewed
+    //         block -- are tallied in registers and reduced through the wave (20 Ki same-address LDS atomics
+    //         cost more than everything else in this kernel together); the rest uses LDS atomics.
+    //   v*  = K-th smallest value among those with count == c*: up to 3 levels of 10 bits below the largest
+    //         value's bit length (levels placed there, not at bit 30, so that the first one already spreads).
     u32* hist = (u32*)sel;  // 1024 bins, reuses the (not yet used) selection buffer (T*8 >= 4096 B
                             // needs T >= 512; for T = 256 the buffer is sized for 512 entries)
     // returns bucket index; *before = total of the buckets passed before it
@@ -290,65 +292,114 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         for (u32 i = tid; i < nbins; i += nt) hist[i] = 0;
         __syncthreads();
     };
+    auto wave_sum = [&](u32 v) -> u32 {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    };
     u32 before;
-    // ---- c*: level 1 (count >> 7), level 2 (count & 127), scanned from the top
-    clear_hist(256);
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-        const u32 c = count_of(i);
-        if (c) atomicAdd(&hist[c >> 7], 1u);
+    // ---- c*
+    const u32 CAPC = nb / T + 1;  // counts >= CAPC exceed every possible c*
+    clear_hist(CAPC + 1);
+    {
+        u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
+            const u32 c = count_of(i);
+            n1 += c == 1 ? 1u : 0u;
+            n2 += c == 2 ? 1u : 0u;
+            n3 += c == 3 ? 1u : 0u;
+            n4 += c == 4 ? 1u : 0u;
+            if (c > 4) atomicAdd(&hist[c < CAPC ? c : CAPC], 1u);
+        }
+        n1 = wave_sum(n1);
+        n2 = wave_sum(n2);
+        n3 = wave_sum(n3);
+        n4 = wave_sum(n4);
+        if ((tid & 63) == 0) {
+            // (bins 1..4 exist: CAPC >= 4 whenever a count of 4 can be below it, else they fold into bin CAPC)
+            if (n1) atomicAdd(&hist[1 < CAPC ? 1 : CAPC], n1);
+            if (n2) atomicAdd(&hist[2 < CAPC ? 2 : CAPC], n2);
+            if (n3) atomicAdd(&hist[3 < CAPC ? 3 : CAPC], n3);
+            if (n4) atomicAdd(&hist[4 < CAPC ? 4 : CAPC], n4);
+        }
     }
-    const u32 B1 = find_bucket(129, T, true, &before);
-    const u32 above1 = before;
-    clear_hist(128);
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-        const u32 c = count_of(i);
-        if (c && (c >> 7) == B1) atomicAdd(&hist[c & 127], 1u);
-    }
-    const u32 b2 = find_bucket(128, T - above1, true, &before);
-    const u32 cstar = (B1 << 7) | b2;
-    const u32 G = above1 + before;   // values with count > c*: all selected
+    const u32 cstar = find_bucket(CAPC + 1, T, true, &before);  // bin CAPC itself cannot be the answer: c* < CAPC
+    const u32 G = before;            // values with count > c*: all selected
     const u32 K = T - G;             // K smallest values with count == c*
     __syncthreads();
-    const u32 ties = hist[b2];
+    const u32 ties = hist[cstar];
     u32 vstar = 0xFFFFFFFFu;  // values at the threshold count are selected iff value <= vstar
     if (ties > K) {
-        clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-            const u32 k = keys[i];
-            if (k != ANSX_RF_EMPTY && count_of(i) == cstar) atomicAdd(&hist[k >> 20], 1u);
+        const u32 nbits = 32u - (u32)__builtin_clz(vmax | 1u);
+        u32 shift = nbits > 10 ? nbits - 10 : 0;  // level 1: the top 10 bits that occur
+        u32 prefix = 0, pshift = 32, need = K;    // candidates so far: (value >> pshift) == prefix
+        for (;;) {
+            clear_hist(1024);
+            for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
+                const u32 k = keys[i];
+                if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (pshift >= 32 || (k >> pshift) == prefix))
+                    atomicAdd(&hist[(k >> shift) & 1023u], 1u);
+            }
+            const u32 V = find_bucket(1024, need, false, &before);
+            need -= before;
+            prefix = pshift >= 32 ? V : ((prefix << (pshift - shift)) | V);
+            pshift = shift;
+            if (shift == 0) break;
+            shift = shift > 10 ? shift - 10 : 0;
         }
-        const u32 V1 = find_bucket(1024, K, false, &before);
-        const u32 k1 = K - before;
-        clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-            const u32 k = keys[i];
-            if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 20) == V1) atomicAdd(&hist[(k >> 10) & 1023], 1u);
-        }
-        const u32 V2 = find_bucket(1024, k1, false, &before);
-        const u32 k2 = k1 - before;
-        const u32 hi20 = (V1 << 10) | V2;
-        clear_hist(1024);
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-            const u32 k = keys[i];
-            if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (k >> 10) == hi20) atomicAdd(&hist[k & 1023], 1u);
-        }
-        const u32 V3 = find_bucket(1024, k2, false, &before);
-        vstar = (hi20 << 10) | V3;
+        vstar = prefix;
     }
     __syncthreads();
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
-        const u32 k = keys[i];
-        if (k == ANSX_RF_EMPTY) continue;
-        const u32 c = count_of(i);
-        if (c > cstar || (c == cstar && k <= vstar)) {
-            const u32 slot = atomicAdd(&sh_cnt, 1u);
-            if (slot < T) sel[slot] = ((u64)(0xFFFFFFFFu - c) << 32) | (u64)k;  // (-count, value)
+    // ---- collect the T selected (count, value) pairs: one LDS atomic per wave and round
+    for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) {
+        const u32 i = i0 + tid;
+        u32 k = ANSX_RF_EMPTY, c = 0;
+        if (i < ANSX_RF_SLOTS) {
+            k = keys[i];
+            c = count_of(i);
+        }
+        const bool take = k != ANSX_RF_EMPTY && (c > cstar || (c == cstar && k <= vstar));
+        const u64 m = __builtin_amdgcn_ballot_w64(take);
+        if (m) {
+            u32 basep = 0;
+            if ((tid & 63) == (u32)__builtin_ctzll(m)) basep = atomicAdd(&sh_cnt, (u32)__builtin_popcountll(m));
+            basep = __shfl(basep, (int)__builtin_ctzll(m));
+            const u32 slot = basep + (u32)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
+            if (take && slot < T) sel[slot] = ((u64)(0xFFFFFFFFu - c) << 32) | (u64)k;  // (-count, value)
         }
     }
     __syncthreads();
-    lds_bitonic_sort<u64>(sel, T, tid, nt);
+    // ---- sort them by (-count, value).  T <= 1024: one element per thread, bitonic network; a stage whose
+    // partner distance is below 64 stays inside the wave (two shuffles, no LDS round trip, no barrier) -- 45 of
+    // the 55 stages of a 1024-element sort
+    if (T <= nt) {
+        u64 key = tid < T ? sel[tid] : ~0ull;
+        for (u32 k = 2; k <= T; k <<= 1) {
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                u64 other;
+                if (j >= 64) {
+                    __syncthreads();
+                    if (tid < T) sel[tid] = key;
+                    __syncthreads();
+                    other = tid < T ? sel[tid ^ j] : ~0ull;
+                } else {
+                    const u32 lo = (u32)__shfl_xor((int)(u32)key, (int)j);
+                    const u32 hi = (u32)__shfl_xor((int)(u32)(key >> 32), (int)j);
+                    other = ((u64)hi << 32) | lo;
+                }
+                const bool asc = (tid & k) == 0, lower = (tid & j) == 0;
+                const bool keep_min = asc == lower;
+                key = keep_min ? (key < other ? key : other) : (key < other ? other : key);
+            }
+        }
+        __syncthreads();
+        if (tid < T) sel[tid] = key;
+        __syncthreads();
+    } else {
+        lds_bitonic_sort<u64>(sel, T, tid, nt);
+    }
     for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += nt) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
     __syncthreads();
     u32* mf = mostfreq + (u64)b * T;

@@ -717,7 +717,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         // (measured on MI355X, 256 Mi ints: rings 0.73 vs 0.76 ms at 16 Ki / 1024, 0.73 vs 1.85 ms at
         // 64 Ki / 1024 where the stream no longer fits; staged 0.60 vs 0.69 ms at 16 Ki / 512 -- the
         // ring bookkeeping costs ~6 VALU per step, so it only pays when it frees a lot of LDS)
-        const size_t ring_lds = (size_t)(threads / 4) * ANSX_RING_BYTES + 512;  // + alignment slack
+        const size_t ring_lds = (size_t)(threads / 4) * ANSX_RING_STRIDE + 16;  // + alignment slack
         const bool staged_fits = rs_tables + want_stream <= 52 * 1024;
         const bool ring_ok = g.ckpt != 0 && g.block_ints % g.ckpt == 0 && g.ckpt % 4 == 0
             && rs_tables + ring_lds <= 60 * 1024;

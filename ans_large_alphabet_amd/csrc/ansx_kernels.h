@@ -2377,32 +2377,34 @@ __global__ __launch_bounds__(64) void k_parse_prelude_par(const u8* __restrict__
 #define ANSX_RING_CHK 4
 #endif
 #define ANSX_RING_BYTES (128 * ANSX_RING_CHK)
+#define ANSX_RING_STRIDE (ANSX_RING_BYTES + 16)  // + 8 mirror bytes (ring bytes 0..7 once more) and padding to 16
+// end8 = end - 8: the decoder keeps its cursor biased by 8, so this is what its prefix sum yields
 template <int MODE>
-__device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end)
+__device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end8)
 {
     if (MODE == 1) {
         // lds_stream word 0 holds stream bytes [-8,-4): byte a of the stream is at lds byte a+8
-        const u32 a = (u32)end;  // = (end - 8) + 8
-        const u32 w = a >> 2, sh = a & 3;
-        const u32 w0 = lds_stream[w], w1 = lds_stream[w + 1], w2 = lds_stream[w + 2];
+        const int w = end8 >> 2;  // >= -2: the two guard words
+        const u32 sh = (u32)end8 & 3u;
+        const u32 w0 = lds_stream[w + 2], w1 = lds_stream[w + 3], w2 = lds_stream[w + 4];
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
         const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
         return ((u64)hi << 32) | lo;
     } else if (MODE == 2) {
-        // lds_stream = this quad's ring, 512-byte aligned in LDS: stream byte s lives at ring byte
-        // s & 511, so each of the three word addresses is one bit-field insert into the ring's base
+        // lds_stream = this quad's ring: stream byte s lives at ring byte s & (RB - 1), and ring bytes 0..7 are
+        // kept once more behind the ring, so the three words that cover the 8 bytes are contiguous wherever
+        // they start: one address, ds_read2_b32 + ds_read_b32
         typedef __attribute__((address_space(3))) const u32 lds_cu32;
         const u32 rb = (u32)(size_t)(__attribute__((address_space(3))) const void*)lds_stream;
-        const u32 a = (u32)end;
-        const u32 m = ANSX_RING_BYTES - 4;  // word-aligned offset bits
-        const u32 a0 = ((a - 8) & m) | (rb & ~m), a1 = ((a - 4) & m) | (rb & ~m), a2 = (a & m) | (rb & ~m);
-        const u32 w0 = *(lds_cu32*)(size_t)a0, w1 = *(lds_cu32*)(size_t)a1, w2 = *(lds_cu32*)(size_t)a2;
+        const u32 a = (u32)end8;
+        lds_cu32* wp = (lds_cu32*)(size_t)(rb + (a & (ANSX_RING_BYTES - 4)));
+        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
         const u32 sh = a & 3;
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
         const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
         return ((u64)hi << 32) | lo;
     } else {
-        return ld_u64_unaligned(stream + end - 8);
+        return ld_u64_unaligned(stream + end8);
     }
 }
 
@@ -2445,18 +2447,20 @@ struct dec_lut_table {
     }
 };
 struct dec_lut_rank {
-    const uint2* bwp;  // {bitmap word, set bits before it}
+    const uint2* bwp;  // {bitmap word, (set bits before it) - 1 + (LDS byte address of ep) / 8}
     const uint2* ep;   // per present symbol: {base << 16 | freq, k << 30 | value without its exception bytes}
+    // the second word of a bitmap entry, see above (ep is 8-byte aligned)
+    __device__ __forceinline__ u32 bias() const { return (u32)(size_t)(__attribute__((address_space(3))) const void*)ep / 8u - 1u; }
     __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
     {
         const uint2 wp = bwp[slot >> 5];
         // bits [0, slot & 31] of the word: shift the rest out at the top (the shifter uses the low
-        // five bits of ~slot = 31 - (slot & 31))
-        const u32 r = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y - 1u;
-        const uint2 e = ep[r];  // one 8-byte LDS read
-        pv = e.y;
-        fr = e.x & 0xFFFFu;
-        base = e.x >> 16;
+        // five bits of ~slot = 31 - (slot & 31)); v_bcnt adds the biased prefix: the entry's address / 8
+        const u32 r8 = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y;
+        const u64 e = *(__attribute__((address_space(3))) const u64*)(size_t)(r8 << 3);  // one 8-byte LDS read
+        pv = (u32)(e >> 32);
+        fr = (u32)e & 0xFFFFu;
+        base = (u32)e >> 16;
     }
 };
 
@@ -2466,9 +2470,14 @@ struct dec_lut_rank {
 // every lane the quad's counts S, v_sad_u8 adds the bytes of S & lomask (lanes before this one) or
 // of S (all four) onto q.
 struct dec_quad_const {
-    u32 ql8;     // 8 * ql
-    u32 lomask;  // (1 << 8 ql) - 1
+    u32 ql8;       // 8 * ql
+    u32 lomask;    // (1 << 8 ql) - 1
+    u32 four_pos;  // 4 << 8 ql
 };
+__device__ __forceinline__ dec_quad_const dec_make_qc(u32 ql) { return dec_quad_const{ 8 * ql, (1u << (8 * ql)) - 1u, 4u << (8 * ql) }; }
+// q = 8 - (byte cursor): the sums below then yield (position - 8), where the 8 bytes a lane needs start
+#define ANSX_DEC_Q(p) ((u32)(8 - (int)(p)))
+#define ANSX_DEC_P(q) (8 - (int)(q))
 template <int STREAM_LDS, typename LUT>
 __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_quad_const qc, u32 logM, u32 mask,
     u64 Lb, const LUT& lut, const u8* __restrict__ stream, const u32* lds_stream)
@@ -2477,26 +2486,28 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     u32 fr, base, pv;
     lut.get(slot, fr, base, pv);
     // ans_fold.hpp:218-220: fr * (st >> logM) + (slot - base).  st < 2^52 for frames up to 2^16, so
-    // the high word of the quotient is small: one 32x32->64 mad plus a 24-bit multiply-add
+    // the high word of the quotient is small: one 32x32->64 mad, and a 24-bit mad into its high word
     const u64 qs = st >> logM;
-    u64 ns_ = (u64)fr * (u32)qs + (u64)(slot - base);
-    ns_ += (u64)__umul24(fr, (u32)(qs >> 32)) << 32;
+    const u64 t = (u64)fr * (u32)qs + (u64)(slot - base);
+    u64 ns_ = ((u64)((u32)(t >> 32) + __umul24(fr, (u32)(qs >> 32))) << 32) | (u32)t;
     const bool rn = active && (ns_ < Lb);
     const u32 k = pv >> 30;
-    const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
-    const u32 s1 = quad_add_perm<1, 0, 3, 2>(c << qc.ql8);
-    const u32 S = quad_add_perm<2, 3, 0, 1>(s1);
-    int myp = -(int)__builtin_amdgcn_sad_u8(S & qc.lomask, 0u, q);
+    const u32 cq = active ? ((k << qc.ql8) + (rn ? qc.four_pos : 0u)) : 0u;
+    const u32 s1 = quad_add_dpp<0xB1>(cq);
+    const u32 S = quad_add_dpp<0x4E>(s1);
+    int myp8 = -(int)__builtin_amdgcn_sad_u8(S & qc.lomask, 0u, q);
     q = __builtin_amdgcn_sad_u8(S, 0u, q);
-    myp = myp < 0 ? 0 : myp;
-    const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp);
+    // a corrupt stream can drive the cursor below 0: the ring wraps every address into itself, the
+    // other sources have 8 guard bytes in front and clamp
+    if (STREAM_LDS != 2) myp8 = myp8 < -8 ? -8 : myp8;
+    const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp8);
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
     if (rn) ns_ = (ns_ << 32) | hi;  // ans_fold.hpp:221-225
     if (active) st = ns_;
-    // the k exception bytes sit just below the renorm word (or at the top when there is none):
-    // the top k bytes of lo resp. hi; v_bfe with width 0 yields 0 for k = 0
-    const u32 k8 = k << 3;
-    const u32 e = __builtin_amdgcn_ubfe(rn ? lo : hi, 32u - k8, k8);
+    // the k exception bytes sit just below the renorm word (or at the top when there is none): the top k
+    // bytes of lo resp. hi = that word, zero-extended to 64 bits, shifted right by 32 - 8k (0 for k = 0).
+    // (Added, not OR-ed: an ANSrfold value has T subtracted and its low 8k bits are no longer zero.)
+    const u32 e = (u32)((u64)(rn ? lo : hi) >> (32u - 8u * k));
     return (pv & ANSX_PV_MASK) + e;
 }
 
@@ -2508,7 +2519,7 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
 {
     const u32 nseg = geo_nseg(nb, g.ckpt);
     const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
-    const dec_quad_const qc = { 8 * ql, (1u << (8 * ql)) - 1u };
+    const dec_quad_const qc = dec_make_qc(ql);
     const u64 Lb = (u64)16 << logM;
     const u32 mask = (1u << logM) - 1;
     const u32 rtail = nb & 3, nfull = nb - rtail;
@@ -2524,7 +2535,7 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
             u32 po = ckpt_off[idx];
             p = (int)(po < sbytes ? po : sbytes);
         }
-        u32 q = (u32)(-p);
+        u32 q = ANSX_DEC_Q(p);
         const u32 start = seg * g.ckpt;
         u32 end = (seg == nseg - 1) ? nfull : (start + g.ckpt);
         end = end < nfull ? end : nfull;
@@ -2554,7 +2565,7 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
             int pf_front = p;
             u32 pf = 0;
             for (u32 i = start; i < end; i += 4) {
-                if (-(int)q - 256 < pf_front) {
+                if (ANSX_DEC_P(q) - 256 < pf_front) {
                     asm volatile("" ::"v"(pf));
                     int a = pf_front - 128 * (int)(ql + 1);
                     a = a < 0 ? 0 : a;
@@ -2617,10 +2628,10 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
     static_assert(T >= 32 + 2 * 28 * CHK, "ring too small for the worst-case consumption");
     const u32 nseg = g.block_ints / g.ckpt;  // uniform segments (checked by the caller)
     const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
-    const dec_quad_const qc = { 8 * ql, (1u << (8 * ql)) - 1u };
+    const dec_quad_const qc = dec_make_qc(ql);
     const u64 Lb = (u64)16 << logM;
     const u32 mask = (1u << logM) - 1;
-    u32* ring = rings + quad * (RB / 4);
+    u32* ring = rings + quad * (ANSX_RING_STRIDE / 4);
     u8* ring8 = (u8*)ring;
     const u32 steps = g.ckpt >> 2;
     const int lane_off = (R / 4) * (int)ql;  // this lane's share of a refill
@@ -2636,7 +2647,7 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
             u32 po = ckpt_off[idx];
             p = (int)(po < sbytes ? po : sbytes);
         }
-        u32 q = (u32)(-p);
+        u32 q = ANSX_DEC_Q(p);
         // initial window [lo, lo + RB) with p - lo in [T, T + R/4): RB/64 pieces per lane.  lo is a
         // multiple of the lane share, so a lane's pieces never straddle the ring's end.
         int lo = (p - T) & ~(R / 4 - 1);
@@ -2648,7 +2659,9 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
 #pragma unroll
             for (int j = 0; j < RB / 64; j++) {
                 asm volatile("" : "+v"(r[j]));  // keep the dependence on the asm loads behind the wait
-                *(ansx_u32x4*)(ring8 + ((u32)(lo + (RB / 4) * (int)ql + 16 * j) & (RB - 1))) = r[j];
+                const u32 d = (u32)(lo + (RB / 4) * (int)ql + 16 * j) & (RB - 1);
+                *(ansx_u32x4*)(ring8 + d) = r[j];
+                if (d == 0) *(uint2*)(ring8 + RB) = make_uint2(r[j].x, r[j].y);  // second copy of ring bytes 0..7
             }
         }
         u32* op = o + seg * g.ckpt + ql;
@@ -2662,6 +2675,7 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
                 const u32 d0 = (u32)(lo + lane_off) & (RB - 1);
 #pragma unroll
                 for (int j = 0; j < NP; j++) *(ansx_u32x4*)(ring8 + d0 + 16 * j) = rr[j];  // aligned share: no wrap inside
+                if (d0 == 0) *(uint2*)(ring8 + RB) = make_uint2(rr[0].x, rr[0].y);  // second copy of ring bytes 0..7
             }
         };
         u32 i = 0;
@@ -2670,7 +2684,7 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
             if constexpr (CHK == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
             else asm volatile("s_waitcnt vmcnt(2)" : "+v"(rr[0])::"memory");
             land();
-            const int cur = -(int)q;
+            const int cur = ANSX_DEC_P(q);
             pending = (cur - lo) < T;
 #pragma unroll
             for (int j = 0; j < NP; j++) rr[j] = ring_load16(D, lo - R + lane_off + 16 * j, pending);
@@ -2812,7 +2826,9 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
             const u32 t = __shfl_up(incl, d);
             if ((int)tid >= d) incl += t;
         }
-        u32 run = incl - loc;
+        dec_lut_rank bl;
+        bl.ep = ep;
+        u32 run = incl - loc + bl.bias();
         for (u32 i = 0; i < per; i++)
             if (lo + i < W) {
                 bwp[lo + i].y = run;
@@ -2836,9 +2852,9 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         if (span > room) span = room;
         const u64 ba = (u64)(uintptr_t)base;
         D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
-        // rings start at the next ring-size boundary of the LDS address space (the host adds the slack)
+        // rings start at the next 16-byte boundary of the LDS address space (the host adds the slack)
         const u32 labs = (u32)(size_t)(__attribute__((address_space(3))) void*)lds_stream;
-        u32* rings = lds_stream + ((((labs + (ANSX_RING_BYTES - 1)) & ~(u32)(ANSX_RING_BYTES - 1)) - labs) >> 2);
+        u32* rings = lds_stream + ((((labs + 15u) & ~15u) - labs) >> 2);
         dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o);
     } else if (st_lds)
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);

@@ -61,8 +61,9 @@ enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
 // through ansx_last_encode_stats, so a flip cannot go unnoticed.
 __device__ __forceinline__ bool ansx_near_threshold(double XH, double thr)
 {
+    // (a single-symbol block has H = XH = 0 exactly on both sides -- log2(1) -- and is not a close call)
     const double d = XH - thr;
-    return (d < 0 ? -d : d) <= 1e-12 * thr;
+    return thr > 0.0 && (d < 0 ? -d : d) <= 1e-12 * thr;
 }
 enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     const double thr = B->thr;
     int prev = B->prev;
     int chosen = -2;
+    u32 near = 0;
     // all candidates' results in one round trip (lane t holds attempt t), then the sequential rule
     uint4 mt = make_uint4(0u, 0u, 0u, 0u);
     if (lane < ANSX_ATTEMPTS) mt = *(const uint4*)(attMeta + ((u64)b * ANSX_ATTEMPTS + lane) * 4);
@@ -631,13 +633,14 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             break;
         }
         const double XH = ansx_bits_to_f64((u64)m2 | ((u64)m3 << 32));
-        if (lane == 0 && ansx_near_threshold(XH, thr)) atomicAdd(&gflags[ANSX_G_NEAR], 1u);
+        near += ansx_near_threshold(XH, thr) ? 1u : 0u;
         if (XH < thr) {  // ans_util.hpp:149
             chosen = (int)T;
             break;
         }
         prev = (int)T;
     }
+    if (lane == 0 && near) atomicAdd(&gflags[ANSX_G_NEAR], near);
     if (chosen == -2) {
         // still undecided after this batch: remember the last rejected success
         if (prev >= (int)(batch * ANSX_ATTEMPTS)) {

@@ -2618,10 +2618,41 @@ __device__ __forceinline__ ansx_u32x4 ring_load16(const dec_ring_desc& D, int s,
     return r;
 }
 
+// What a quad needs before it can decode its first segment -- restart state, cursor and the initial ring window --
+// requested BEFORE the block's tables are built, so that the two dependent round trips (restart point, then the
+// stream bytes it points at) overlap the table build instead of following it.
+struct dec_ring_pre {
+    u64 st;
+    int p, lo;
+    ansx_u32x4 r[ANSX_RING_BYTES / 64];
+};
+__device__ __forceinline__ void dec_ring_prefetch(dec_ring_pre& P, const ansx_geo& g, u32 b, u32 sbytes, u32 tid,
+    u32 logM, const u8* __restrict__ stream, const dec_ring_desc& D, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off)
+{
+    constexpr int RB = ANSX_RING_BYTES, R = 32 * ANSX_RING_CHK, T = RB - R - 16;
+    const u32 seg = tid >> 2, ql = tid & 3;
+    const u32 nseg = g.block_ints / g.ckpt;
+    P.st = 0;
+    P.p = 0;
+    if (seg == 0) {  // ans_fold.hpp:289-295: states 3,2,1,0 from the end
+        P.st = ld_u64_unaligned(stream + sbytes - 32 + 8 * (3 - ql)) + ((u64)16 << logM);
+        P.p = (int)sbytes - 32;
+    } else if (seg < nseg) {
+        const u64 idx = (u64)b * g.nckf + (seg - 1);
+        P.st = ckpt_state[idx * 4 + (3 - ql)];
+        const u32 po = ckpt_off[idx];
+        P.p = (int)(po < sbytes ? po : sbytes);
+    }
+    P.lo = (P.p - T) & ~(R / 4 - 1);
+#pragma unroll
+    for (int j = 0; j < RB / 64; j++) P.r[j] = ring_load16(D, P.lo + (RB / 4) * (int)ql + 16 * j, seg < nseg);
+}
+
 template <typename LUT>
 __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 sbytes, u32 tid, u32 nt,
     u32 logM, const LUT& lut, const u8* __restrict__ stream, u32* rings, const dec_ring_desc& D,
-    const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o)
+    const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o, dec_ring_pre& P)
 {
     constexpr int RB = ANSX_RING_BYTES, CHK = ANSX_RING_CHK;
     constexpr int R = 32 * CHK;        // bytes per refill, 8 * CHK per lane
@@ -2641,23 +2672,27 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
     for (u32 seg = quad; seg < nseg; seg += nq) {
         u64 st;
         int p;
-        if (seg == 0) {  // ans_fold.hpp:289-295: states 3,2,1,0 from the end
-            st = ld_u64_unaligned(stream + sbytes - 32 + 8 * (3 - ql)) + Lb;
-            p = (int)sbytes - 32;
+        int lo;
+        // initial window [lo, lo + RB) with p - lo in [T, T + R/4): RB/64 pieces per lane.  lo is a
+        // multiple of the lane share, so a lane's pieces never straddle the ring's end.
+        ansx_u32x4 r[RB / 64];
+        if (seg == quad) {  // the quad's first segment: requested by dec_ring_prefetch before the table build
+            st = P.st;
+            p = P.p;
+            lo = P.lo;
+#pragma unroll
+            for (int j = 0; j < RB / 64; j++) r[j] = P.r[j];
         } else {
-            const u64 idx = (u64)b * g.nckf + (seg - 1);
+            const u64 idx = (u64)b * g.nckf + (seg - 1);  // (seg >= nq > 0)
             st = ckpt_state[idx * 4 + (3 - ql)];
             u32 po = ckpt_off[idx];
             p = (int)(po < sbytes ? po : sbytes);
-        }
-        u32 q = ANSX_DEC_Q(p);
-        // initial window [lo, lo + RB) with p - lo in [T, T + R/4): RB/64 pieces per lane.  lo is a
-        // multiple of the lane share, so a lane's pieces never straddle the ring's end.
-        int lo = (p - T) & ~(R / 4 - 1);
-        {
-            ansx_u32x4 r[RB / 64];
+            lo = (p - T) & ~(R / 4 - 1);
 #pragma unroll
             for (int j = 0; j < RB / 64; j++) r[j] = ring_load16(D, lo + (RB / 4) * (int)ql + 16 * j, true);
+        }
+        u32 q = ANSX_DEC_Q(p);
+        {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < RB / 64; j++) {
@@ -2733,13 +2768,24 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     __shared__ u32 sh_bad;
     const u32 tid = threadIdx.x, nt = blockDim.x;
     const u32 b = blockIdx.x;
+    // Everything the table build needs from HBM is requested before anything is waited for: the block's parse
+    // results, its stream bounds and the first 4 nt parsed inc[] values (a row of g_cum has NSP + 8 entries
+    // whatever the block's alphabet; values beyond it are masked below) -- one round trip instead of three.
+    const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
+    u32 cur4[4], prv4[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+        const u32 s = q * nt + tid;
+        cur4[q] = s < NSP ? gc[s + 1] : 0u;
+        prv4[q] = (s < NSP && s) ? gc[s] : 0u;
+    }
     const uint4 bi = binfo[b];
+    const u64 boff = block_off[b], boff1 = block_off[b + 1];
     if (bi.w) return;  // parse error already flagged
     const u32 ns = bi.x, logM = bi.y, rflag = bi.z;
     const u32 nb = geo_block_n(g, b);
-    const u64 boff = block_off[b];
     const u8* stream = cont + payload_off + boff;
-    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const u32 sbytes = (u32)(boff1 - boff);
     const ansx_map f = g.map;
     const u32 T = fold_T(g.f);
     const u32 M = 1u << logM;
@@ -2752,6 +2798,23 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     off += 2 * ((max_ns * 4 + 15) & ~15u);  // (same bytes as the host's 2 x rup(4 max_ns, 16))
     u32* lds_stream = (u32*)(smem + off);
     const u32 W = M >= 32 ? M / 32 : 1;
+    // full block: all segments have g.ckpt ints (host-checked), each quad's first one is requested now
+    const bool use_ring = RING && nb == g.block_ints;
+    dec_ring_desc D;
+    dec_ring_pre RP;
+    if (use_ring) {
+        // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
+        // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
+        const u64 sabs = payload_off + boff;  // stream offset inside the container
+        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
+        const u8* base = cont + (sabs - (u64)D.backoff);
+        u64 span = (u64)D.backoff + sbytes + 64;
+        const u64 room = stream_cap - (sabs - (u64)D.backoff);  // container bytes from base on
+        if (span > room) span = room;
+        const u64 ba = (u64)(uintptr_t)base;
+        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
+        dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
+    }
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
     if (tid == 0) sh_bad = 0;
     const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
@@ -2765,16 +2828,23 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     // inside the round was most of this kernel's time on 2300-symbol alphabets).
     {
         __shared__ u64 sh_scan[8];
-        const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
         u64 carry = 0;
         u32 bad = 0;
         for (u32 c0 = 0; c0 < ns; c0 += 4 * nt) {
-            u32 cur4[4], prv4[4];
+            // this chunk's values were requested one chunk ago (the first: at kernel start); request the next
+            u32 c4[4], p4[4], nx4[4] = {}, np4[4] = {};
 #pragma unroll
             for (u32 q = 0; q < 4; q++) {
-                const u32 s = c0 + q * nt + tid;
-                cur4[q] = s < ns ? gc[s + 1] : 0u;
-                prv4[q] = (s < ns && s) ? gc[s] + 1u : 0u;
+                c4[q] = cur4[q];
+                p4[q] = (c0 + q * nt + tid) ? prv4[q] + 1u : 0u;
+            }
+            if (c0 + 4 * nt < ns) {
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) {
+                    const u32 s = c0 + 4 * nt + q * nt + tid;
+                    nx4[q] = s < ns ? gc[s + 1] : 0u;
+                    np4[q] = s < ns ? gc[s] : 0u;
+                }
             }
 #pragma unroll
             for (u32 q = 0; q < 4; q++) {
@@ -2782,8 +2852,8 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
                 if (c0 + q * nt >= ns) break;  // uniform
                 u32 fr = 0;
                 if (s < ns) {
-                    fr = cur4[q] - prv4[q];
-                    if (cur4[q] < prv4[q] || fr > M || fr > 0xFFFFu) {  // entries hold 16-bit freq and base
+                    fr = c4[q] - p4[q];
+                    if (c4[q] < p4[q] || fr > M || fr > 0xFFFFu) {  // entries hold 16-bit freq and base
                         bad = 1;
                         fr = 0;
                     }
@@ -2808,6 +2878,11 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
                     }
                 }
             }
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                cur4[q] = nx4[q];
+                prv4[q] = np4[q];
+            }
         }
         if ((carry & 0xFFFFFFFFull) != M || (carry >> 32) > max_ns) bad = 1;
         if (bad) {
@@ -2816,7 +2891,10 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         }
     }
     __syncthreads();
-    if (sh_bad) return;
+    if (sh_bad) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the prefetched window is still on its way)
+        return;
+    }
     if (tid < 64) {  // running popcount before every bitmap word
         const u32 per = (W + 63) / 64;
         const u32 lo = tid * per;
@@ -2843,22 +2921,11 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     lut.bwp = bwp;
     lut.ep = ep;
     u32* o = outp + (u64)b * g.block_ints;
-    if (RING && nb == g.block_ints) {  // full block: all segments have g.ckpt ints (host-checked)
-        // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
-        // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
-        const u64 sabs = payload_off + boff;  // stream offset inside the container
-        dec_ring_desc D;
-        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
-        const u8* base = cont + (sabs - (u64)D.backoff);
-        u64 span = (u64)D.backoff + sbytes + 64;
-        const u64 room = stream_cap - (sabs - (u64)D.backoff);  // container bytes from base on
-        if (span > room) span = room;
-        const u64 ba = (u64)(uintptr_t)base;
-        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
+    if (use_ring) {
         // rings start at the next 16-byte boundary of the LDS address space (the host adds the slack)
         const u32 labs = (u32)(size_t)(__attribute__((address_space(3))) void*)lds_stream;
         u32* rings = lds_stream + ((((labs + 15u) & ~15u) - labs) >> 2);
-        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o);
+        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o, RP);
     } else if (st_lds)
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else

@@ -21,13 +21,13 @@ acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collect
 for f in glob.glob(out+'/sq*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name'].split('(')[0]
-        if 'k_encode' not in k and 'k_decode' not in k: continue
         acc[k][r['Counter_Name']]+=float(r['Counter_Value']); cnt[k][r['Counter_Name']]+=1
-for k in acc:
-    w=acc[k].get('SQ_WAVES',1)/max(1,cnt[k].get('SQ_WAVES',1))
-    print(k, 'waves/launch', w)
-    for c in sorted(acc[k]):
-        if c=='SQ_WAVES': continue
-        v=acc[k][c]/cnt[k][c]
-        print('   %-32s %14.1f per launch  %12.1f per wave'%(c, v, v/w))
+for k in sorted(acc):
+    a={c:acc[k][c]/cnt[k][c] for c in acc[k]}
+    w=a.get('SQ_WAVES',1)
+    g=lambda c:a.get(c,0.0)
+    wc=g('SQ_WAVE_CYCLES') or 1.0
+    print('%-34s waves %7d  cyc/wave %9.0f  insts/wave %8.0f (valu %7.0f lds %6.0f vmem %6.0f salu %6.0f)  active: any %.2f valu %.2f lds %.2f vmem %.2f  wait_inst %.2f wait_any %.2f  busy_cyc %.0f'%(
+        k[:34], w, 4*wc/w, g('SQ_INSTS')/w, g('SQ_INSTS_VALU')/w, g('SQ_INSTS_LDS')/w, (g('SQ_INSTS_VMEM_WR')+g('SQ_INSTS_VMEM_RD'))/w, g('SQ_INSTS_SALU')/w,
+        g('SQ_ACTIVE_INST_ANY')/wc, g('SQ_ACTIVE_INST_VALU')/wc, g('SQ_ACTIVE_INST_LDS')/wc, g('SQ_ACTIVE_INST_VMEM')/wc, g('SQ_WAIT_INST_ANY')/wc, g('SQ_WAIT_ANY')/wc, 4*g('SQ_BUSY_CYCLES')))
 PY

@@ -211,10 +211,17 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     }
     __syncthreads();
     auto count_of = [&](u32 slot) -> u32 { return (cnt32[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu; };
-    // ---- insert: value -> count (counts <= 16384 fit 16 bits)
+    // ---- insert: value -> count (counts <= 16384 fit 16 bits).  A thread's values (16 at 1024 threads and
+    // 16 Ki-int blocks) are requested together: one at a time, each insert waited a global round trip.
+    constexpr u32 RF_VPT = 16;
+    u32 vals[RF_VPT];
+#pragma unroll
+    for (u32 q = 0; q < RF_VPT; q++) {
+        const u32 i = tid + q * nt;
+        vals[q] = i < nb ? src[i] : 0u;
+    }
     u32 lmax = 0, ldistinct = 0;
-    for (u32 i = tid; i < nb; i += nt) {
-        const u32 v = src[i];
+    auto insert_one = [&](u32 v) {
         lmax = v > lmax ? v : lmax;
         u32 slot = rf_slot(v);
         for (;;) {
@@ -224,7 +231,11 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
             slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
         }
         atomicAdd(&cnt32[slot >> 1], 1u << (16 * (slot & 1)));
-    }
+    };
+#pragma unroll
+    for (u32 q = 0; q < RF_VPT; q++)
+        if (tid + q * nt < nb) insert_one(vals[q]);
+    for (u32 i = tid + RF_VPT * nt; i < nb; i += nt) insert_one(src[i]);  // (fewer than 1024 threads)
     atomicMax(&sh_max, lmax);
     atomicAdd(&sh_cnt, ldistinct);
     __syncthreads();
@@ -352,22 +363,30 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     __syncthreads();
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
-    // ---- collect the T selected (count, value) pairs: one LDS atomic per wave and round
-    for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) {
-        const u32 i = i0 + tid;
-        u32 k = ANSX_RF_EMPTY, c = 0;
-        if (i < ANSX_RF_SLOTS) {
-            k = keys[i];
-            c = count_of(i);
-        }
-        const bool take = k != ANSX_RF_EMPTY && (c > cstar || (c == cstar && k <= vstar));
-        const u64 m = __builtin_amdgcn_ballot_w64(take);
-        if (m) {
-            u32 basep = 0;
-            if ((tid & 63) == (u32)__builtin_ctzll(m)) basep = atomicAdd(&sh_cnt, (u32)__builtin_popcountll(m));
-            basep = __shfl(basep, (int)__builtin_ctzll(m));
-            const u32 slot = basep + (u32)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
+    // ---- collect the T selected (count, value) pairs: every wave counts its share, reserves it with ONE LDS
+    // atomic and fills it in slot order (an atomic per round and wave was a dependent LDS round trip each)
+    {
+        auto taken = [&](u32 i, u32& k, u32& c) -> bool {
+            k = ANSX_RF_EMPTY;
+            c = 0;
+            if (i < ANSX_RF_SLOTS) {
+                k = keys[i];
+                c = count_of(i);
+            }
+            return k != ANSX_RF_EMPTY && (c > cstar || (c == cstar && k <= vstar));
+        };
+        u32 mine = 0, k, c;
+        for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) mine += taken(i0 + tid, k, c) ? 1u : 0u;
+        const u32 wtotal = wave_sum(mine);
+        u32 run = 0;
+        if ((tid & 63) == 0) run = atomicAdd(&sh_cnt, wtotal);
+        run = (u32)__shfl((int)run, 0);
+        for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) {
+            const bool take = taken(i0 + tid, k, c);
+            const u64 m = __builtin_amdgcn_ballot_w64(take);
+            const u32 slot = run + (u32)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
             if (take && slot < T) sel[slot] = ((u64)(0xFFFFFFFFu - c) << 32) | (u64)k;  // (-count, value)
+            run += (u32)__builtin_popcountll(m);
         }
     }
     __syncthreads();
@@ -412,8 +431,8 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         atomicAnd(&cnt32[slot >> 1], ~(0xFFFFu << (16 * (slot & 1))) | (r << (16 * (slot & 1))));
     }
     __syncthreads();
-    for (u32 i = tid; i < nb; i += nt) {
-        const u32 v = src[i];
+    // (the values are still in registers)
+    auto remap_one = [&](u32 i, u32 v) {
         u32 slot = rf_slot(v);
         // every value was inserted above, so the probe ends at its slot; the bound only matters if
         // the caller's buffer changes under us (a race on the caller's side must not hang the GPU)
@@ -424,7 +443,11 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         }
         const u32 r = probes < ANSX_RF_SLOTS ? count_of(slot) : 0xFFFFu;
         dst[i] = (r != 0xFFFFu) ? r : v + T;  // :99-103
-    }
+    };
+#pragma unroll
+    for (u32 q = 0; q < RF_VPT; q++)
+        if (tid + q * nt < nb) remap_one(tid + q * nt, vals[q]);
+    for (u32 i = tid + RF_VPT * nt; i < nb; i += nt) remap_one(i, src[i]);
     if (tid == 0) blk[b].flag = 1;
 }
 

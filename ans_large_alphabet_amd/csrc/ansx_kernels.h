@@ -6,9 +6,10 @@
 //               k_scale_attempts   one lane per (block, frame size): scale_freqs + cross entropy          ans_util.hpp:77-95, util.hpp:284-298
 //               k_select_model     stop rule + compact encoder table                                      ans_util.hpp:127-153, ans_fold.hpp:82-91
 //            K3 k_write_prelude    vbyte + log2 M + parallel interpolative coder                          ans_util.hpp:46-63, interp.hpp:28-79
-//            K5 k_encode<MODE>     quad of lanes per block, 4 interleaved states, branch-free step        ans_fold.hpp:100-120,249-278
+//            K5 k_encode<MODE, POW2>  quad of lanes per block, 4 interleaved states, branch-free step;     ans_fold.hpp:100-120,249-278
+//                                  MODE 1: main loop written out operation by operation (4 strands)
 //            K6 k_scan_sizes / k_compact / k_write_header   container assembly
-//   decode:  K7 k_parse_prelude_fast / k_parse_prelude   one lane per block                              ans_util.hpp:25-42, interp.hpp:47-63,81-118
+//   decode:  K7 k_parse_prelude_par (8 lanes per block on the container's parse hints) / _win / _fast / generic   ans_util.hpp:25-42, interp.hpp:47-63,81-118
 //            K8 k_decode_rank<RFOLD, RING> (k_decode: slot->symbol fallback)   quad per restart segment   ans_fold.hpp:179-228,283-311
 //   rfold:   ansx_rfold.h (value remap in front of K1, ans_reorder_fold.hpp:70-106)
 // DESIGN.md section 5 describes each kernel and the hardware facts they are built around.

@@ -1313,7 +1313,7 @@ template <> struct enc_tab<true> {
 // select, ldexp, trunc, mul, trunc, fma with clamp, fma), byte emission, the table-entry arithmetic of the
 // NEXT symbol (B) and the fold map + LDS reads of the symbol three steps ahead (A) -- with a scheduling barrier
 // after each line, 44 VALU instructions per symbol (58.8 before).  What was measured on the way
-// (tests/tools/ubench_valu.hip, in-kernel s_memtime traces):
+// (tests/tools/ubench_valu.hip, ubench_distance.hip, replay_encoder_loop.py, in-kernel s_memtime traces):
 //  * a lone wave issues one VALU instruction per ~4.6 cycles; 8.4 / 6.1 / 5.5 if a source was written 1 / 2 / 3
 //    instructions earlier;
 //  * replayed from registers, this step costs 210 cycles (254 with its LDS reads and stores); inside the kernel
@@ -1568,7 +1568,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                         // One operation per line, a scheduling barrier after each: the order written is the order
                         // issued.  A lone wave issues an instruction every ~4.6 cycles if none of its sources was
                         // written by one of the THREE instructions before it; otherwise it loses a slot
-                        // (tests/tools/ubench_valu.hip: 8.4 / 6.1 / 5.5 / 4.6 cycles per operation at dependency
+                        // (tests/tools/ubench_distance.hip: 8.4 / 6.1 / 5.5 / 4.6 cycles per operation at dependency
                         // distance 1 / 2 / 3 / 4).  Four strands are therefore rotated, one operation each per
                         // row, so that consecutive operations of a strand are four slots apart:
                         //   [C] the state chain of this symbol      [E] its byte emission

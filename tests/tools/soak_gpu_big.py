@@ -22,10 +22,10 @@ fails = 0
 stream = None  # the context's own stream: must order against torch's default stream by itself
 for it in range(24):
     c = it % 6
-    if c == 0: d_in = bench.gen_zipf(torch, n, 20, 1.2, 100 + it, dev)
+    if c == 0: d_in = bench.gen_input(torch, A, ctx, "zipf20s1.2", n, 100 + it, dev)
     elif c == 1: d_in = torch.randint(1 << 24, (1 << 30) - 1, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)   # k = 3 everywhere
     elif c == 2: d_in = torch.randint(0, 256, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
-    elif c == 3: d_in = bench.gen_zipf(torch, n, 24, 1.0, 200 + it, dev)
+    elif c == 3: d_in = bench.gen_input(torch, A, ctx, "zipf24s1.0", n, 200 + it, dev)
     elif c == 4: d_in = (torch.randint(0, 2, (n,), generator=g, device=dev, dtype=torch.int64) * ((1 << 30) - 1)).to(torch.int32)
     else: d_in = torch.randint(0, 1 << 16, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
     kind = [("fold", 1), ("fold", 1), ("fold", 3), ("rfold", 1)][it % 4]

@@ -38,6 +38,7 @@ struct Layout {  // container layout, a pure function of the geometry
 }  // namespace
 
 struct ansx_ctx {
+    u32 num_cus = 256;
     int device = 0;
     hipStream_t stream = nullptr;
     int last_hip = 0;
@@ -437,12 +438,22 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // 31-bit offsets)
     const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull && !test_fixup;
     if (f64_ok && enc_lds <= 40 * 1024) {
+        // Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves per
+        // workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
+        const u32 enc_waves = (NB + 15) / 16;
+        u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
+        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
+        const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
+        if (wpw * enc_lds > 48 * 1024) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+        }
         if (map_is_pow2(g.map))
-            LAUNCH(c, "k_encode", (k_encode<1, true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
                 (u64)scr_stride, ck_state, ck_off);
         else
-            LAUNCH(c, "k_encode", (k_encode<1, false>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
                 (u64)scr_stride, ck_state, ck_off);
     } else if (f64_ok && !c->dbg.encode_gtab16) {
@@ -578,12 +589,22 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     const u32 lds_stride = ns_cap | 1u;  // odd stride spreads the 16 tables over the banks
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
     if (enc_lds <= 40 * 1024) {
+        // Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves per
+        // workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
+        const u32 enc_waves = (NB + 15) / 16;
+        u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
+        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
+        const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
+        if (wpw * enc_lds > 48 * 1024) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+        }
         if (map_is_pow2(g.map))
-            LAUNCH(c, "k_encode", (k_encode<1, true>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
                 (u64)scr_stride, ck_state, ck_off);
         else
-            LAUNCH(c, "k_encode", (k_encode<1, false>), ((size_t)NB * 4 + 63) / 64, 64, enc_lds, s, src, g, NSP,
+            LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
                 (u64)scr_stride, ck_state, ck_off);
     } else {
@@ -975,6 +996,7 @@ int ansx_init(int device, ansx_ctx** out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ANSX_ERR_NO_DEVICE;  // gfx950-only code object
     ansx_ctx* c = new ansx_ctx();
     c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? (u32)prop.multiProcessorCount : 256u;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
         delete c;
         return ANSX_ERR_HIP;

@@ -1353,13 +1353,17 @@ template <int CTRL> __device__ __forceinline__ u32 quad_add_dpp(u32 v)
 //         the next sub-batch are fetched with inline-asm loads and consumed behind exact vmcnt
 //         waits (24 = the stores of one sub-batch, 32 = the input prefetch of a super-batch)
 template <int MODE, bool POW2 = false>
-__global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
+__global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
     u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
 {
     extern __shared__ u32 lds_tab[];
-    const u32 gt = blockIdx.x * 64 + threadIdx.x;
+    // a workgroup is 1 wave (MODE 0, 2) or 4 waves (MODE 1, EXPERIMENT: kept in step by a barrier per super-batch)
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (blockDim.x >> 6) + wv) * 16));  // first block of this wave (uniform)
+    u32* const wtab = lds_tab + wv * 16 * lds_stride;
+    const u32 gt = wb0 * 4 + lane;
     const u32 b = gt >> 2, ql = gt & 3;
     constexpr bool LDS_TABLE = MODE == 1;
     constexpr bool F64 = MODE != 0;
@@ -1369,7 +1373,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
         // lds_stride - 1 entries plus a zero sentinel (MODE 2).  Two rows per round, every load of a round in
         // flight before the first LDS write (row by row behind a dependent load of the alphabet size this took
         // 90 k cycles, 6 % of the kernel).
-        const u32 b0 = blockIdx.x * 16;
+        const u32 b0 = wb0;
         const u32 take = MODE == 2 ? lds_stride - 1 : lds_stride;
         const u32 lim = take < NSP ? take : NSP;
         for (u32 j = 0; j < 16; j += 2) {
@@ -1380,21 +1384,21 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
             u32 v0[10], v1[10];
 #pragma unroll
             for (int i = 0; i < 10; i++) {
-                const u32 e = threadIdx.x + 64 * i;
+                const u32 e = lane + 64 * i;
                 v0[i] = e < lim ? r0[e] : 0u;
                 v1[i] = e < lim ? r1[e] : 0u;
             }
 #pragma unroll
             for (int i = 0; i < 10; i++) {
-                const u32 e = threadIdx.x + 64 * i;
+                const u32 e = lane + 64 * i;
                 if (e < take) {
-                    lds_tab[j * lds_stride + e] = v0[i];
-                    if (two) lds_tab[(j + 1) * lds_stride + e] = v1[i];
+                    wtab[j * lds_stride + e] = v0[i];
+                    if (two) wtab[(j + 1) * lds_stride + e] = v1[i];
                 }
             }
-            if (MODE == 2 && threadIdx.x == 0) {
-                lds_tab[j * lds_stride + take] = 0;
-                if (two) lds_tab[(j + 1) * lds_stride + take] = 0;
+            if (MODE == 2 && lane == 0) {
+                wtab[j * lds_stride + take] = 0;
+                if (two) wtab[(j + 1) * lds_stride + take] = 0;
             }
         }
         __syncthreads();
@@ -1408,23 +1412,23 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
     const u32 nb = geo_block_n(g, b);
     const u32* src = in + (u64)b * g.block_ints;
     enc_tab<F64> tab;
-    if constexpr (MODE == 1) tab.t = lds_tab + (threadIdx.x >> 2) * lds_stride;
+    if constexpr (MODE == 1) tab.t = wtab + (lane >> 2) * lds_stride;
     else if constexpr (MODE == 2) {
         tab.t = tab32 + (u64)b * NSP;
-        tab.hot = lds_tab + (threadIdx.x >> 2) * lds_stride;
+        tab.hot = wtab + (lane >> 2) * lds_stride;
         const u32 own = B->max_sym + 1;
         tab.nhot = own < lds_stride - 1 ? own : lds_stride - 1;  // entries of THIS block that were staged
         tab.sent = lds_stride - 1;
-        tab.rowoff = (threadIdx.x >> 2) * NSP * 4;
-        const u64 ba = (u64)(uintptr_t)(tab32 + (u64)(blockIdx.x * 16) * NSP);
+        tab.rowoff = (lane >> 2) * NSP * 4;
+        const u64 ba = (u64)(uintptr_t)(tab32 + (u64)wb0 * NSP);
         tab.trs = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, 16u * NSP * 4u, 0x00020000u };
     } else tab.t = table + (u64)b * NSP;
     u8* out = scratch + (u64)b * scr_stride;
     // buffer view of the wave's 16 scratch slots (the host guarantees 16 * scr_stride < 2^31 for
     // the LDS variant): wave-uniform descriptor, per-lane 32-bit offsets
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        scratch + (u64)(blockIdx.x * 16) * scr_stride, 0, (int)(16 * scr_stride), 0x00020000);
-    const u32 obase = (u32)((threadIdx.x >> 2) * scr_stride);
+        scratch + (u64)wb0 * scr_stride, 0, (int)(16 * scr_stride), 0x00020000);
+    const u32 obase = (u32)((lane >> 2) * scr_stride);
     const ansx_map f = g.map;  // value -> symbol map
     const u32 logM = B->logM;
     const u64 Lb = (u64)16 << logM;
@@ -1488,13 +1492,13 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                 // 63 operations in flight, so anything with more than 63 younger operations has completed: no
                 // wait is needed (and none could name it).  A lane whose block has no further group computes a
                 // negative offset, i.e. one beyond num_records: the load returns 0, whose table lookups are harmless.
-                const u64 iba = (u64)(uintptr_t)(in + (u64)(blockIdx.x * 16) * g.block_ints);
-                const u64 irem = g.n - (u64)(blockIdx.x * 16) * g.block_ints;
+                const u64 iba = (u64)(uintptr_t)(in + (u64)wb0 * g.block_ints);
+                const u64 irem = g.n - (u64)wb0 * g.block_ints;
                 const u32 inrec = (u32)((irem < 16ull * g.block_ints ? irem : 16ull * g.block_ints) * 4);
                 const ansx_u32x4 irs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)iba),
                     (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(inrec), 0x00020000u };
                 // byte offset of group (gi - 32), this lane's state, in that view
-                u32 vcur = (threadIdx.x >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (gi - ANSX_ENC_XB);
+                u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (gi - ANSX_ENC_XB);
                 u32 xa[ANSX_ENC_XB];
 #define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
 #pragma unroll
@@ -1506,7 +1510,7 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                                  "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
                 // the quad's table as 16-bit halves (freq, base), read with two ds_read_u16: no unpacking on the
                 // VALU.  Issued as inline asm: the halves are consumed two steps later behind ONE hand-counted wait.
-                const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)lds_tab + 4 * (threadIdx.x >> 2) * lds_stride;
+                const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)wtab + 4 * (lane >> 2) * lds_stride;
                 const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
                 // stage A: value -> (k, symbol), the two halves of its table word requested from LDS
                 auto stage_a = [&](u32 x) {
@@ -1547,7 +1551,10 @@ __global__ __launch_bounds__(64) void k_encode(const u32* __restrict__ in, ansx_
                 encp_e ec = stage_b(a0);
                 double sd = L.sd;
                 u32 pcur = L.p;
+                // every block of the workgroup is a full one: the same number of super-batches for all its waves
+                const bool wg_sync = blockDim.x > 64 && (u64)(blockIdx.x + 1) * (blockDim.x >> 2) * g.block_ints <= g.n;
                 while (gi) {
+                    if (wg_sync) __syncthreads();
                     const u32 top = gi;
                     const u32 vnext = vcur - 16 * ANSX_ENC_XB;
 #pragma unroll

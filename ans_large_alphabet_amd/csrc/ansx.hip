@@ -458,7 +458,13 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
                 (u64)scr_stride, ck_state, ck_off);
     } else if (f64_ok && !c->dbg.encode_gtab16) {
         // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
-        LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, (size_t)16 * ANSX_ENC_HOT * 4, s, src, g, NSP,
+        const u32 w2 = (NB + 15) / 16;
+        u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
+        wpw2 = wpw2 < 1 ? 1 : (wpw2 > 4 ? 4 : wpw2);
+        const size_t lds2 = (size_t)wpw2 * 16 * ANSX_ENC_HOT * 4;
+        if (lds2 > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);
     } else {
@@ -608,7 +614,13 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
                 (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
                 (u64)scr_stride, ck_state, ck_off);
     } else {
-        LAUNCH(c, "k_encode_gtab", (k_encode<2>), ((size_t)NB * 4 + 63) / 64, 64, (size_t)16 * ANSX_ENC_HOT * 4, s, src, g, NSP,
+        const u32 w2 = (NB + 15) / 16;
+        u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
+        wpw2 = wpw2 < 1 ? 1 : (wpw2 > 4 ? 4 : wpw2);
+        const size_t lds2 = (size_t)wpw2 * 16 * ANSX_ENC_HOT * 4;
+        if (lds2 > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
             (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
             (u64)scr_stride, ck_state, ck_off);
     }

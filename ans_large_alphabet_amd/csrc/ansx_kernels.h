@@ -1689,7 +1689,10 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
 #pragma unroll
             for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j], raw1l[j]);
         }
+        // (waves of one workgroup stay in step, see the scheduled loop above)
+        const bool wg_sync2 = blockDim.x > 64 && (u64)(blockIdx.x + 1) * (blockDim.x >> 2) * g.block_ints <= g.n;
         while (gi) {
+            if (wg_sync2) __syncthreads();
             const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
             const bool any_next = __builtin_amdgcn_ballot_w64(top >= 2 * ANSX_ENC_XB) != 0;  // wave uniform
             if (top >= 2 * ANSX_ENC_XB) {

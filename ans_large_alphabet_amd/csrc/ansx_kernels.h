@@ -1359,7 +1359,10 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
 {
     extern __shared__ u32 lds_tab[];
-    // a workgroup is 1 wave (MODE 0, 2) or 4 waves (MODE 1, EXPERIMENT: kept in step by a barrier per super-batch)
+    // A workgroup is 1 to 4 waves, each with its own 16 blocks and tables.  With 1024 single-wave workgroups the
+    // dispatcher does not put a CU's four on four different SIMDs, and waves that run the same long loop out of
+    // phase compete for the CU's instruction fetch: four waves per workgroup land one per SIMD (0.94 -> 0.79 ms on
+    // the headline workload) and a barrier per super-batch keeps them in step (-> 0.70 ms).
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (blockDim.x >> 6) + wv) * 16));  // first block of this wave (uniform)
     u32* const wtab = lds_tab + wv * 16 * lds_stride;

@@ -135,7 +135,10 @@ def pmc_traffic(kernel, workload):
         if best.get("workload") != workload:
             return None, "%s profiles a different workload (%s)" % (rel, best.get("workload"))
         for name, v in best["kernels"].items():
-            if name.split("<")[0] == kernel:
+            base = name.split("<")[0]
+            # profile labels are the launch sites' ("k_decode", "k_encode_gtab"), the PMC summary has the
+            # kernels' own names ("k_decode_rank<...>", "k_encode<2, ...>")
+            if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode"):
                 return v["hbm_bytes"], "replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
         return None, "%s has no entry for %s" % (rel, kernel)
     except Exception as exc:  # noqa: BLE001

@@ -825,6 +825,33 @@ def test_full_size_configs_roundtrip_and_spot_blocks(A, ctx, kind, f, spec):
         assert np.array_equal(parts["ckpt_off"][b][:k], off) and np.array_equal(parts["ckpt_state"][b][:k], st), (spec, b)
 
 
+@pytest.mark.parametrize("mi", [180, 250])
+def test_encoder_multi_wave_workgroups_with_ragged_end(A, ctx, mi):
+    """The encoder packs 3 resp. 4 waves into a workgroup at these sizes and keeps them in step with a barrier --
+    except in the last workgroup, which is only partly filled and ends in a partial block."""
+    import torch
+
+    n = mi * (1 << 20) + 4097
+    d_in = torch.empty(n, dtype=torch.int32, device="cuda")
+    A.generate_dev(ctx, "zipf20s1.2", d_in.data_ptr(), n, seed=77 + mi)
+    codec = codec_for(A, ctx, ol.FOLD, 1, block_ints=16384, ckpt_interval=1024)
+    d_out = torch.empty(codec.bound(n), dtype=torch.uint8, device="cuda")
+    d_back = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel())
+    codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n)
+    assert bool(torch.equal(d_back, d_in))
+    parts = A.parse_container(d_out[:nb].cpu().numpy())
+    nblocks = (n + 16383) // 16384
+    assert parts["header"].nblocks == nblocks
+    rng = np.random.default_rng(mi)
+    for b in sorted(set([0, 63, 64, nblocks - 66, nblocks - 17, nblocks - 2, nblocks - 1] + [int(x) for x in rng.integers(0, nblocks, 9)])):
+        lo, hi = b * 16384, min(n, (b + 1) * 16384)
+        exp, info, st, off = ol.oracle_encode(ol.FOLD, 1, d_in[lo:hi].cpu().numpy().view(np.uint32), ckpt_interval=1024)
+        assert np.array_equal(parts["streams"][b], exp), b
+        assert np.array_equal(parts["ckpt_state"][b][:st.shape[0]], st), b
+
+
 PA_FAMS = ["zipf20s1.2", "uniform256", "geom0.01", "uniform20", "constant", "boundaries_small", "runs"]
 
 

@@ -686,10 +686,35 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     // host already knows such a consumer will run (always16) -- or later through k_table16_from32
     const bool write16 = always16 || (B->m0_log2 + (u32)chosen) > 16;
     u32 carry = 0;
-    for (u32 s0 = 0; s0 < ns; s0 += 64) {
+    // (alphabets of up to 640 symbols: the histogram and the chosen frequencies of all rounds are requested before
+    // the first scan -- a round trip per 64 symbols made this 1-wave-per-block kernel 47 us per block)
+    constexpr u32 SEL_PRE = 10;
+    u32 hpre[SEL_PRE], spre[SEL_PRE];
+    const bool pre = ns <= 64 * SEL_PRE;
+    if (pre) {
+#pragma unroll
+        for (u32 r = 0; r < SEL_PRE; r++) {
+            const u32 s = r * 64 + lane;
+            hpre[r] = s < ns ? h[s] : 0u;
+            spre[r] = s < ns ? (u32)S[(u64)s * sstride] : 0u;
+        }
+    }
+    for (u32 s0 = 0, r = 0; s0 < ns; s0 += 64, r++) {
         const u32 s = s0 + lane;
-        const u32 hv = s < ns ? h[s] : 0u;
-        const u32 sv = s < ns ? (u32)S[(u64)s * sstride] : 0u;
+        u32 hv, sv;
+        if (pre) {
+            hv = 0;
+            sv = 0;
+#pragma unroll
+            for (u32 q = 0; q < SEL_PRE; q++)
+                if (q == r) {
+                    hv = hpre[q];
+                    sv = spre[q];
+                }
+        } else {
+            hv = s < ns ? h[s] : 0u;
+            sv = s < ns ? (u32)S[(u64)s * sstride] : 0u;
+        }
         const u32 fr = hv ? sv : 0u;
         u32 incl = fr;
 #pragma unroll

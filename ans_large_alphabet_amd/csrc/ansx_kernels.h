@@ -240,12 +240,20 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     double* terms = (double*)(hrow + NSP);   // [512], only allocated when the entropy is summed here
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
-    const u32 ns = blk[b].max_sym + 1;
     const u32* h = hist + (u64)b * NSP;
+    // stage the histogram row once: its first 640 entries are requested together with the alphabet size they are
+    // then cut to (a row has NSP entries whatever the block's alphabet) -- one round trip instead of two or more
+    constexpr u32 SORT_PRE = 10;
+    u32 hp[SORT_PRE];
+#pragma unroll
+    for (u32 r = 0; r < SORT_PRE; r++) hp[r] = r * 64 + lane < NSP ? h[r * 64 + lane] : 0u;
+    const u32 ns = blk[b].max_sym + 1;
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
-    // stage the histogram row once (coalesced, all loads in flight together)
-    for (u32 s = lane; s < ns; s += 64) hrow[s] = h[s];
+#pragma unroll
+    for (u32 r = 0; r < SORT_PRE; r++)
+        if (r * 64 + lane < ns) hrow[r * 64 + lane] = hp[r];
+    for (u32 s = SORT_PRE * 64 + lane; s < ns; s += 64) hrow[s] = h[s];
     for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
     for (u32 v = lane; v < ANSX_MASKV; v += 64) vmask[v] = 0;
     if (lane == 0) sh_nbig = 0;

@@ -1015,6 +1015,13 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const u32 tid = threadIdx.x;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
+    // (small alphabets: the table row is requested together with the block's fields, not after them)
+    const u32* t32 = tab32 + (u64)b * NSP;
+    u32 epre[4] = {};
+    if (SMALL) {
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) epre[r] = tid + 256 * r < NSP ? t32[tid + 256 * r] : 0u;
+    }
     if (B->status || !B->resolved || B->pa_sigma == 1) {  // (unresolved: optimistic single-batch call, the host repeats it)
         if (tid == 0) {
             B->prelude_bytes = B->pa_sigma == 1 ? B->pre_bytes : 0;  // a one-value block is its alphabet header
@@ -1027,10 +1034,14 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     u32* bits = lds32 + NSP;  // bit buffer
     u32* inc = SMALL ? lds32 + 2 * NSP : incbuf + (u64)b * NSP;
     if (SMALL) {
-        const u32* t32 = tab32 + (u64)b * NSP;
-        for (u32 s = tid; s < ns; s += 256) {
+#pragma unroll
+        for (u32 r = 0; r < 4; r++) {
+            const u32 s = tid + 256 * r;
+            if (s < ns) inc[s] = (epre[r] >> 16) + (epre[r] & 0xFFFFu) + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+        }
+        for (u32 s = tid + 1024; s < ns; s += 256) {
             const u32 e = t32[s];
-            inc[s] = (e >> 16) + (e & 0xFFFFu) + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+            inc[s] = (e >> 16) + (e & 0xFFFFu) + s;
         }
     } else {
         const ansx_enc_entry* tab = table + (u64)b * NSP;

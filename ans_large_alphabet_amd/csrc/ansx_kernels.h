@@ -109,11 +109,23 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     if ((((uintptr_t)src) & 15u) == 0) {
         const uint4* v4 = (const uint4*)src;
         const u32 nvec = len >> 2;
-        // 8 independent 16-byte loads in flight per thread before any of them is consumed: the
+        // 16 (a whole 16 Ki-int chunk: one round trip) independent 16-byte loads in flight per thread before any of them is consumed: the
         // kernel is a latency chain otherwise (measured: 4 % VALU activity, 64 % of the wave's
         // cycles in s_waitcnt with one load per iteration)
         u32 v = tid;
-        for (; v + 7 * 256 < nvec; v += 8 * 256) {
+        for (; v + 15 * 256 < nvec; v += 16 * 256) {
+            uint4 q[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) q[j] = v4[v + j * 256];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                take(q[j].x);
+                take(q[j].y);
+                take(q[j].z);
+                take(q[j].w);
+            }
+        }
+        for (; v + 7 * 256 < nvec; v += 8 * 256) {  // (smaller chunks)
             uint4 q[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) q[j] = v4[v + j * 256];

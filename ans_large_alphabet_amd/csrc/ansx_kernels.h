@@ -423,17 +423,25 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 }
 
 // Stage-1 results of ansx_log2_portable for x = 1 .. 65535 (entry 0 unused): one table per context.
-struct ansx_log2_ent {
+// 16 bytes per entry = one load per lookup: the exponent part of stage 1 is cheap to derive from the operand
+// (ansx_log2_e_of_int, checked against ansx_log2_stage1 for every x), and the candidate kernel is bound by the
+// address unit's rate on exactly these 64-line gathers.
+struct __attribute__((aligned(16))) ansx_log2_ent {
     double y, ylo;
-    int e, pad;
 };
+// e of ansx_log2_stage1 for an integer 1 <= x <= 65535: its exponent, + 1 when the mantissa exceeds sqrt(2)
+__device__ __forceinline__ int ansx_log2_e_of_int(u32 x)
+{
+    const int msb = 31 - (int)__builtin_clz(x | 1u);
+    return msb + (((double)x > __builtin_ldexp(1.4142135623730951, msb)) ? 1 : 0);
+}
 __global__ void k_build_log2_lut(ansx_log2_ent* __restrict__ lut)
 {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 65536u) return;
     ansx_log2_ent r;
-    r.pad = 0;
-    ansx_log2_stage1((double)(i ? i : 1u), &r.e, &r.y, &r.ylo);
+    int e;
+    ansx_log2_stage1((double)(i ? i : 1u), &e, &r.y, &r.ylo);
     lut[i] = r;
 }
 
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
             const double p = valid ? ansx_div_int31((double)h8[u], nd) : 0.0;
-            const double lg = ansx_log2_stage2(le[u].e - (int)sh, le[u].y, le[u].ylo);
+            const double lg = ansx_log2_stage2(ansx_log2_e_of_int(s8[u]) - (int)sh, le[u].y, le[u].ylo);
             tm[u] = p * (valid ? lg : 0.0);  // absent: p * log2(1) = +0.0
         }
 #pragma unroll

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
                     const ansx_log2_ent* le = l2lut + sv;
                     e.y[u] = le->y;
                     e.ylo[u] = le->ylo;
-                    e.e[u] = le->e;
+                    e.e[u] = ansx_log2_e_of_int(sv);
                 }
                 return e;
             };

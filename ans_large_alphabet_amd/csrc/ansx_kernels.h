@@ -2391,19 +2391,23 @@ __global__ __launch_bounds__(64) void k_parse_prelude_win(const u8* __restrict__
 // payload: offsets are bounds-checked, and a wrong one yields a table that fails the decoder's
 // consistency checks or decodes to garbage, never an out-of-range access.
 template <bool RFOLD, u32 SW>
-__global__ __launch_bounds__(64) void k_parse_prelude_par(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+__global__ __launch_bounds__(256) void k_parse_prelude_par(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, u64 payload_off, u32 max_ns, u32 maxM, const u32* __restrict__ hints,
     u32* __restrict__ g_cum, uint4* __restrict__ binfo, u32* __restrict__ gflags, const uint4* __restrict__ pa_info)
 {
-    // SW staged words per lane (a subtree's share of a prelude is ~35 bytes at 530 symbols, ~130 at 2300).
-    // Measured on MI355X, 16384 blocks: SW = 64 0.166 / 0.284 ms, SW = 32 0.180 / 0.262 ms for those two shapes
-    // (the kernel is VALU-issue bound machine-wide -- ~125 instructions per item -- so it gains over one
-    // lane per block only where that form leaves SIMDs idle: 3.4x on the large alphabets, nothing on the small).
-    __shared__ u32 stage[SW][64];
-    __shared__ u32 stkA[16][64], stkL[16][64], stkH[16][64];  // subtrees of <= 2048 items: depth <= 12; row 15 = dump
-    const u32 lane = threadIdx.x;
+    // SW staged words per lane (a subtree's share of a prelude is ~35 bytes at 530 symbols, ~130 at 2300); the host
+    // launches SW = 32.  The kernel is VALU-issue bound machine-wide (~125 instructions per item).
+    // Up to four waves per workgroup, each on its own slice of the dynamic LDS and never synchronised with the
+    // others: like the encoder's, single-wave workgroups pile up unevenly on a CU's SIMDs once a CU holds more
+    // than two of them (0.036 ms up to 2 per CU, 0.103 at 4, 0.168 at 8); see the launch site for the sweep.
+    extern __shared__ u32 par_lds[];
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 (*stage)[64] = (u32 (*)[64])(par_lds + wv * ((SW + 48) * 64));
+    u32 (*stkA)[64] = stage + SW;   // subtrees of <= 2048 items: depth <= 12; row 15 = dump
+    u32 (*stkL)[64] = stkA + 16;
+    u32 (*stkH)[64] = stkL + 16;
     const u32 j = lane & 7;                      // lane within the block's group
-    const u32 b = blockIdx.x * 8 + (lane >> 3);
+    const u32 b = (blockIdx.x * (blockDim.x >> 6) + wv) * 8 + (lane >> 3);
     const bool live = b < g.nblocks;
     parse_hdr H;
     H.err = 1, H.ns = 1, H.logM = 0, H.flag = 0, H.pos = 0, H.sbytes = 0, H.stream = cont;

@@ -440,8 +440,10 @@ struct __attribute__((aligned(16))) ansx_log2_ent {
 // e of ansx_log2_stage1 for an integer 1 <= x <= 65535: its exponent, + 1 when the mantissa exceeds sqrt(2)
 __device__ __forceinline__ int ansx_log2_e_of_int(u32 x)
 {
-    const int msb = 31 - (int)__builtin_clz(x | 1u);
-    return msb + (((double)x > __builtin_ldexp(1.4142135623730951, msb)) ? 1 : 0);
+    // x > 1.4142135623730951 * 2^msb  <=>  x << (31 - msb) > 1.4142135623730951 * 2^31 = 3037000499.97...; the left
+    // side is an integer (< 2^32): integer operations only, this sits in the candidate kernel's inner loop
+    const u32 lz = (u32)__builtin_clz(x | 1u);
+    return (int)(31u - lz) + ((x << lz) >= 3037000500u ? 1 : 0);
 }
 __global__ void k_build_log2_lut(ansx_log2_ent* __restrict__ lut)
 {
@@ -605,6 +607,9 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     const double nd = (double)(int)B.n;
     // q = S / M with M = 2^sh: the division by a power of two is exact, so it is a multiply
     // (sh == 31 would make (int)M negative in util.hpp:289; such frames never reach this point)
+    // p = h / n: a block of 2^k ints (every full block of the default geometry) makes that h * 2^-k, exactly
+    const bool n_pow2 = __all((B.n & (B.n - 1u)) == 0);
+    const double inv_nd = 1.0 / nd;  // (exact when used)
     double acc = 0.0;
     uint4 ha = *(const uint4*)(h), hb = *(const uint4*)(h + 4);
     for (u32 i0 = 0; i0 < ns; i0 += 8) {
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
-            const double p = valid ? ansx_div_int31((double)h8[u], nd) : 0.0;
+            const double p = !valid ? 0.0 : n_pow2 ? (double)h8[u] * inv_nd : ansx_div_int31((double)h8[u], nd);
             const double lg = ansx_log2_stage2(ansx_log2_e_of_int(s8[u]) - (int)sh, le[u].y, le[u].ylo);
             tm[u] = p * (valid ? lg : 0.0);  // absent: p * log2(1) = +0.0
         }

@@ -52,6 +52,8 @@ struct ansx_ctx {
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
     std::map<u64, u32> ns_hint;
+    std::map<u64, u32> rf_hint;  // rfold: most distinct values per block seen per geometry (optimistic hash-table size)
+    u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
     ansx_encode_stats last = {};
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
@@ -230,8 +232,19 @@ int flags_to_status(u32 fl)
 // --------------------------------------------------------------------------------- rfold
 // ans_reorder_fold.hpp:70-106 on the device: LDS hash table per block for blocks <= 16384 ints,
 // HBM hash table for longer blocks (incl. whole-list single-stream mode).
+// Optimistic hash-table size for a geometry whose blocks had at most `distinct` different values so far: 1.5 x that,
+// if two such tables (+ selection buffers) share a CU's LDS; 0 = use the full-size table.
+u32 rf_opt_slots(u32 distinct, u32 T)
+{
+    if (distinct == 0) return 0;
+    u32 slots = (distinct + distinct / 2 + 64 + 255) & ~255u;
+    if (slots < 1024) slots = 1024;
+    const size_t lds = 6 * (size_t)slots + 8 * (size_t)(T < 512 ? 512 : T);
+    return lds <= 78 * 1024 ? slots : 0u;
+}
+// opt_slots != 0: optimistic table size for the LDS form (see k_rfold_remap_hash), from rf_opt_slots()
 int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u32* mostfreq,
-    ansx_blk* blk, u32* gflags, hipStream_t s)
+    ansx_blk* blk, u32* gflags, hipStream_t s, u32 opt_slots = 0)
 {
     const u32 T = fold_T(g.f);
     if (g.block_ints > 16384u) {
@@ -257,11 +270,20 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
         return ANSX_OK;
     }
     if (T <= 4096) {  // hash-table form
-        size_t lds = 6 * (size_t)ANSX_RF_SLOTS + 8 * (size_t)(T < 512 ? 512 : T);  // also holds a 1024-bin histogram
+        const size_t sel_bytes = 8 * (size_t)(T < 512 ? 512 : T);  // also holds a 1024-bin histogram
+        if (opt_slots != 0 && opt_slots < ANSX_RF_SLOTS) {
+            const size_t lds = 6 * (size_t)opt_slots + sel_bytes;
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash2,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash2, g.nblocks, 1024, lds, s, d_in, g, opt_slots, mapped,
+                mostfreq, blk, gflags);
+            return ANSX_OK;
+        }
+        const size_t lds = 6 * (size_t)ANSX_RF_SLOTS + sel_bytes;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash, g.nblocks, 1024, lds, s, d_in, g, mapped, mostfreq,
-            blk, gflags);
+        LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash, g.nblocks, 1024, lds, s, d_in, g, (u32)ANSX_RF_SLOTS, mapped,
+            mostfreq, blk, gflags);
         return ANSX_OK;
     }
     u32 N2 = 2;
@@ -326,7 +348,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         const u32 T = fold_T(f);
         if ((rc = ensure(c, c->mapped, (size_t)g.n * 4))) return rc;
         if ((rc = ensure(c, c->mostfreq, (size_t)NB * T * 4))) return rc;
-        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s);
+        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s, optimistic ? c->cur_rf_slots : 0u);
         if (rc) return rc;
         src = (const u32*)c->mapped.p;
         mostfreq = (const u32*)c->mostfreq.p;
@@ -484,6 +506,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     HIPCHK(c, hipStreamSynchronize(s));
     if (optimistic) {
         if (c->h_pin[ANSX_G_ERR] & (1u << 6)) return ANSX_ERR_DOMAIN;
+        if (c->h_pin[ANSX_G_ERR] & (1u << ANSX_G_VIOL_BIT)) return ANSX_RETRY_GENERAL;  // (rfold: optimistic hash table too small)
         if (c->h_pin[ANSX_G_PAD] != 0 || c->h_pin[ANSX_G_MAXLOGM] > 16 || c->h_pin[ANSX_G_MAXNSYMS] > ns_cap)
             return ANSX_RETRY_GENERAL;
     }
@@ -572,7 +595,7 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
         const u32 T = fold_T(f);
         if ((rc = ensure(c, c->mapped, (size_t)g.n * 4))) return rc;
         if ((rc = ensure(c, c->mostfreq, (size_t)NB * T * 4))) return rc;
-        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s);
+        rc = rfold_remap(c, P.g, d_in, (u32*)c->mapped.p, (u32*)c->mostfreq.p, blk, gflags, s, c->cur_rf_slots);
         if (rc) return rc;
         src = (const u32*)c->mapped.p;
         mostfreq = (const u32*)c->mostfreq.p;
@@ -655,6 +678,8 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
     const bool eligible = !P.plain && hint != 0 && P.NSP <= 4096 && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
         && !c->dbg.model_sync;  // (with compaction too: the hint then describes the alphabets of the rank-remapped blocks)
+    const auto rit = c->rf_hint.find(key);
+    c->cur_rf_slots = (eligible && P.g.kind == ANSX_RFOLD && rit != c->rf_hint.end()) ? rf_opt_slots(rit->second, fold_T(P.g.f)) : 0u;
     if (eligible) {
         u32 ns_cap = (hint + 7u) & ~7u;
         if (ns_cap < 64) ns_cap = 64;
@@ -670,6 +695,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK && !P.g.pa ? 2u : 1u);
     if (rc == ANSX_RETRY_GENERAL) {
         missed = eligible;
+        c->cur_rf_slots = 0;
         path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
@@ -683,6 +709,12 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         const u32 want = missed ? seen + seen / 8 + 8 : seen;
         u32& h = c->ns_hint[key];
         if (want > h) h = want;
+        if (P.g.kind == ANSX_RFOLD) {
+            const u32 d = c->h_pin[ANSX_G_RFDIST];
+            u32& r = c->rf_hint[key];
+            const u32 wantd = missed ? d + d / 8 + 8 : d;
+            if (wantd > r) r = wantd;
+        }
     }
     return rc;
 }

@@ -51,9 +51,11 @@ struct __attribute__((aligned(16))) ansx_enc_entry {
 
 typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
 
+#define ANSX_G_VIOL_BIT 8u  // gflags[ANSX_G_ERR]: the optimistic (hint-sized) path does not apply to this input
 enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
     // (words 4, 5 hold the 64-bit payload size)
-    ANSX_G_NEAR = 6 };  // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
+    ANSX_G_NEAR = 6,    // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
+    ANSX_G_RFDIST = 7 };  // rfold: the most distinct values any block of the call had (sizes the next call's hash tables)
 
 // The one step of the path whose parity with the reference is empirical rather than by construction:
 // log2 is libm's there and ansx_log2_portable here (<= 1 ulp apart), so the decision XH < H * 1.001

@@ -34,7 +34,6 @@
 
 #include "ansx_kernels.h"
 
-#define ANSX_G_VIOL_BIT 8u  // gflags[ANSX_G_ERR]: the optimistic (hint-sized) path does not apply to this input
 
 struct ansx_model_lds {  // byte offsets into the kernel's dynamic LDS (host: model_layout in ansx.hip)
     u32 cap;        // symbol capacity, a multiple of 8

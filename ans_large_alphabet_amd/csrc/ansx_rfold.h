@@ -183,31 +183,37 @@ __global__ __launch_bounds__(256) void k_rfold_remap(const u32* __restrict__ in,
 #define ANSX_RF_SLOTS 20480u  // >= 1.25 x 16384 values per block
 #define ANSX_RF_EMPTY 0xFFFFFFFFu
 
-__device__ __forceinline__ u32 rf_slot(u32 v) { return (u32)(((u64)(v * 2654435761u) * ANSX_RF_SLOTS) >> 32); }
+__device__ __forceinline__ u32 rf_slot(u32 v, u32 slots) { return (u32)(((u64)(v * 2654435761u) * slots) >> 32); }
 
-// Launched with 1024 threads: the table occupies most of a CU's LDS, so this one workgroup is all
-// the latency hiding its ~10 passes over the table get (8.9 -> see DESIGN.md with 256 threads).
-__global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict__ in, ansx_geo g,
+// Launched with 1024 threads: the full-size table (ANSX_RF_SLOTS slots, any block of up to 16 Ki ints) occupies most
+// of a CU's LDS, so this one workgroup is all the latency hiding its ~10 passes over the table get (8.9 -> see
+// DESIGN.md with 256 threads).  A smaller `slots` is the optimistic form: the context has seen this
+// geometry before and sizes the table for 1.5 x the most distinct values a block of it ever had, so that two
+// workgroups share a CU (k_rfold_remap_hash2: 64 registers) and every pass is that much shorter; a block that
+// does not fit raises the violation flag, writes zeros, and the caller repeats the call with the full table.
+__device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in, const ansx_geo& g, u32 slots,
     u32* __restrict__ mapped, u32* __restrict__ mostfreq, ansx_blk* __restrict__ blk,
     u32* __restrict__ gflags)
 {
     extern __shared__ u8 smem_rh[];
     __shared__ u32 sh_cnt;
     __shared__ u32 sh_max;
+    __shared__ u32 sh_ovf;
     const u32 tid = threadIdx.x, nt = blockDim.x;
     const u32 b = blockIdx.x;
     const u32 nb = geo_block_n(g, b);
     const u32 T = fold_T(g.f);
     u32* keys = (u32*)smem_rh;                                      // [SLOTS]
-    u32* cnt32 = (u32*)(smem_rh + 4 * (size_t)ANSX_RF_SLOTS);      // [SLOTS/2], two u16 counters each
-    u64* sel = (u64*)(smem_rh + 6 * (size_t)ANSX_RF_SLOTS);        // [T]
+    u32* cnt32 = (u32*)(smem_rh + 4 * (size_t)slots);              // [slots/2], two u16 counters each
+    u64* sel = (u64*)(smem_rh + 6 * (size_t)slots);                // [T]  (slots is a multiple of 4)
     const u32* src = in + (u64)b * g.block_ints;
     u32* dst = mapped + (u64)b * g.block_ints;
-    for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) keys[i] = ANSX_RF_EMPTY;
-    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += nt) cnt32[i] = 0;
+    for (u32 i = tid; i < slots; i += nt) keys[i] = ANSX_RF_EMPTY;
+    for (u32 i = tid; i < slots / 2; i += nt) cnt32[i] = 0;
     if (tid == 0) {
         sh_cnt = 0;
         sh_max = 0;
+        sh_ovf = 0;
     }
     __syncthreads();
     auto count_of = [&](u32 slot) -> u32 { return (cnt32[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu; };
@@ -223,12 +229,17 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     u32 lmax = 0, ldistinct = 0;
     auto insert_one = [&](u32 v) {
         lmax = v > lmax ? v : lmax;
-        u32 slot = rf_slot(v);
+        u32 slot = rf_slot(v, slots);
+        u32 probes = 0;
         for (;;) {
             const u32 old = atomicCAS(&keys[slot], ANSX_RF_EMPTY, v);
             if (old == ANSX_RF_EMPTY) ldistinct++;
             if (old == ANSX_RF_EMPTY || old == v) break;
-            slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+            slot = slot + 1 == slots ? 0 : slot + 1;
+            if (++probes >= slots) {  // table full (only possible with a table below ANSX_RF_SLOTS)
+                sh_ovf = 1;
+                return;
+            }
         }
         atomicAdd(&cnt32[slot >> 1], 1u << (16 * (slot & 1)));
     };
@@ -239,8 +250,18 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     atomicMax(&sh_max, lmax);
     atomicAdd(&sh_cnt, ldistinct);
     __syncthreads();
+    if (sh_ovf) {  // optimistic table too small: a valid (all-zero, flag 0) block, and the call is repeated
+        for (u32 i = tid; i < nb; i += nt) dst[i] = 0;
+        if (tid == 0) {
+            blk[b].flag = 0;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_VIOL_BIT);
+            atomicMax(&gflags[ANSX_G_RFDIST], slots);  // (at least this many distinct values)
+        }
+        return;
+    }
     const u32 sigma = sh_cnt;
     const u32 vmax = sh_max;
+    if (tid == 0 && sigma > gflags[ANSX_G_RFDIST]) atomicMax(&gflags[ANSX_G_RFDIST], sigma);
     if (sigma < T) {  // ans_reorder_fold.hpp:94-97: identity mapping, flag 0
         for (u32 i = tid; i < nb; i += nt) dst[i] = src[i];
         if (tid == 0) {
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     clear_hist(CAPC + 1);
     {
         u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0;
-        for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
+        for (u32 i = tid; i < slots; i += nt) {
             const u32 c = count_of(i);
             n1 += c == 1 ? 1u : 0u;
             n2 += c == 2 ? 1u : 0u;
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         u32 prefix = 0, pshift = 32, need = K;    // candidates so far: (value >> pshift) == prefix
         for (;;) {
             clear_hist(1024);
-            for (u32 i = tid; i < ANSX_RF_SLOTS; i += nt) {
+            for (u32 i = tid; i < slots; i += nt) {
                 const u32 k = keys[i];
                 if (k != ANSX_RF_EMPTY && count_of(i) == cstar && (pshift >= 32 || (k >> pshift) == prefix))
                     atomicAdd(&hist[(k >> shift) & 1023u], 1u);
@@ -369,19 +390,19 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
         auto taken = [&](u32 i, u32& k, u32& c) -> bool {
             k = ANSX_RF_EMPTY;
             c = 0;
-            if (i < ANSX_RF_SLOTS) {
+            if (i < slots) {
                 k = keys[i];
                 c = count_of(i);
             }
             return k != ANSX_RF_EMPTY && (c > cstar || (c == cstar && k <= vstar));
         };
         u32 mine = 0, k, c;
-        for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) mine += taken(i0 + tid, k, c) ? 1u : 0u;
+        for (u32 i0 = 0; i0 < slots; i0 += nt) mine += taken(i0 + tid, k, c) ? 1u : 0u;
         const u32 wtotal = wave_sum(mine);
         u32 run = 0;
         if ((tid & 63) == 0) run = atomicAdd(&sh_cnt, wtotal);
         run = (u32)__shfl((int)run, 0);
-        for (u32 i0 = 0; i0 < ANSX_RF_SLOTS; i0 += nt) {
+        for (u32 i0 = 0; i0 < slots; i0 += nt) {
             const bool take = taken(i0 + tid, k, c);
             const u64 m = __builtin_amdgcn_ballot_w64(take);
             const u32 slot = run + (u32)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
@@ -419,29 +440,29 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     } else {
         lds_bitonic_sort<u64>(sel, T, tid, nt);
     }
-    for (u32 i = tid; i < ANSX_RF_SLOTS / 2; i += nt) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
+    for (u32 i = tid; i < slots / 2; i += nt) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
     __syncthreads();
     u32* mf = mostfreq + (u64)b * T;
     for (u32 r = tid; r < T; r += nt) {
         const u32 v = (u32)sel[r];
         mf[r] = v;  // ans_reorder_fold.hpp:104-105
-        u32 slot = rf_slot(v);
-        while (keys[slot] != v) slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+        u32 slot = rf_slot(v, slots);
+        while (keys[slot] != v) slot = slot + 1 == slots ? 0 : slot + 1;
         // two ranks share a word: clear this half (0xFFFF -> r) with an atomic AND
         atomicAnd(&cnt32[slot >> 1], ~(0xFFFFu << (16 * (slot & 1))) | (r << (16 * (slot & 1))));
     }
     __syncthreads();
     // (the values are still in registers)
     auto remap_one = [&](u32 i, u32 v) {
-        u32 slot = rf_slot(v);
+        u32 slot = rf_slot(v, slots);
         // every value was inserted above, so the probe ends at its slot; the bound only matters if
         // the caller's buffer changes under us (a race on the caller's side must not hang the GPU)
         u32 probes = 0;
-        while (keys[slot] != v && probes < ANSX_RF_SLOTS) {
-            slot = slot + 1 == ANSX_RF_SLOTS ? 0 : slot + 1;
+        while (keys[slot] != v && probes < slots) {
+            slot = slot + 1 == slots ? 0 : slot + 1;
             probes++;
         }
-        const u32 r = probes < ANSX_RF_SLOTS ? count_of(slot) : 0xFFFFu;
+        const u32 r = probes < slots ? count_of(slot) : 0xFFFFu;
         dst[i] = (r != 0xFFFFu) ? r : v + T;  // :99-103
     };
 #pragma unroll
@@ -451,6 +472,19 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     if (tid == 0) blk[b].flag = 1;
 }
 
+
+__global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict__ in, ansx_geo g, u32 slots,
+    u32* __restrict__ mapped, u32* __restrict__ mostfreq, ansx_blk* __restrict__ blk, u32* __restrict__ gflags)
+{
+    rfold_remap_hash_body(in, g, slots, mapped, mostfreq, blk, gflags);
+}
+// two workgroups per CU: 32 waves, 64 registers each
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rfold_remap_hash2(
+    const u32* __restrict__ in, ansx_geo g, u32 slots, u32* __restrict__ mapped, u32* __restrict__ mostfreq,
+    ansx_blk* __restrict__ blk, u32* __restrict__ gflags)
+{
+    rfold_remap_hash_body(in, g, slots, mapped, mostfreq, blk, gflags);
+}
 
 // ------------------------------------------------------------------------------------------
 // K9 (large blocks, any block_ints < 2^31, e.g. whole-list single-stream mode): the same

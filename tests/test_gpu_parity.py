@@ -140,6 +140,32 @@ def test_rfold_blocks_match_oracle(A, ctx, f, fam):
     assert np.array_equal(codec.decode(cont, n), data)
 
 
+def test_rfold_optimistic_hash_table(A, oracle_built):
+    """The second ANSrfold call of a geometry sizes its per-block hash tables for 1.5 x the most distinct values a
+    block had so far (two workgroups per CU, shorter passes).  Same bytes as the full-size table; a later input
+    whose blocks hold more distinct values than the table has slots (uniform over 2^24: every value of a block
+    differs) overflows it, and the call repeats itself on the full-size path (stats.path & 16) -- still equal to
+    the oracle."""
+    own = A.Context(0)  # a context of its own: the hints are per context and geometry
+    f, n = 3, 5 * 16384 + 777
+    few = ol.gen_inputs("zipf20s1.2", n, seed=3)
+    many = ol.gen_inputs("uniform24", n, seed=4)
+    codec = codec_for(A, own, ol.RFOLD, f, block_ints=16384, ckpt_interval=1024)
+    first = codec.encode(few)                      # discovery: full-size tables
+    check_container(A, first, few, ol.RFOLD, f, 16384, 1024)
+    second = codec.encode(few)                     # optimistic: small tables
+    assert own.last_encode_stats()["path"] & 16 == 0
+    assert np.array_equal(first, second)
+    cont = codec.encode(many)                      # overflows the small tables
+    assert own.last_encode_stats()["path"] & 16
+    check_container(A, cont, many, ol.RFOLD, f, 16384, 1024)
+    assert np.array_equal(codec.decode(cont, n), many)
+    again = codec.encode(many)                     # the hint has grown: full-size tables, no repeat
+    assert own.last_encode_stats()["path"] & 16 == 0
+    assert np.array_equal(cont, again)
+    assert np.array_equal(codec.encode(few), first)
+
+
 @pytest.mark.parametrize("kind", [ol.FOLD, ol.RFOLD])
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 313, 1000, 1001, 4096, 4097])
 def test_small_and_ragged_sizes(A, ctx, kind, n):

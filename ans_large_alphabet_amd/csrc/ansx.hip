@@ -237,7 +237,7 @@ int flags_to_status(u32 fl)
 u32 rf_opt_slots(u32 distinct, u32 T)
 {
     if (distinct == 0) return 0;
-    u32 slots = (distinct + distinct / 2 + 64 + 255) & ~255u;
+    u32 slots = (2 * distinct + distinct / 2 + 64 + 255) & ~255u;
     if (slots < 1024) slots = 1024;
     const size_t lds = 6 * (size_t)slots + 8 * (size_t)(T < 512 ? 512 : T);
     return lds <= 78 * 1024 ? slots : 0u;

@@ -44,10 +44,18 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
         sh_max = 0;
     }
     __syncthreads();
-    // distinct values: first inserter of a value appends it to uq
+    // distinct values: first inserter of a value appends it to uq.  A thread's 16 values (blocks hold at most
+    // 16 Ki ints) are requested together and stay in registers for the ranking pass below: one at a time, each
+    // waited a global round trip that this one workgroup per CU has nothing to hide behind.
+    constexpr u32 PA_VPT = ANSX_PA_MAX_BLOCK / 1024;
+    u32 vals[PA_VPT];
+#pragma unroll
+    for (u32 q = 0; q < PA_VPT; q++) vals[q] = tid + q * nt < nb ? src[tid + q * nt] : 0u;
     u32 lmax = 0;
-    for (u32 i = tid; i < nb; i += nt) {
-        const u32 v = src[i];
+#pragma unroll
+    for (u32 q = 0; q < PA_VPT; q++) {
+        if (tid + q * nt >= nb) break;
+        const u32 v = vals[q];
         lmax = v > lmax ? v : lmax;
         u32 slot = pa_slot(v);
         for (u32 probes = 0; probes < ANSX_PA_SLOTS; probes++) {
@@ -101,8 +109,11 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
         }
     }
     // 1-based rank of every value (:91-103)
-    for (u32 i = tid; i < nb; i += nt) {
-        const u32 v = src[i];
+#pragma unroll
+    for (u32 q = 0; q < PA_VPT; q++) {
+        const u32 i = tid + q * nt;
+        if (i >= nb) break;
+        const u32 v = vals[q];
         u32 lo = 0, hi = sigma;
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;

@@ -18,6 +18,8 @@
 
 #include "ansx_kernels.h"
 
+#include <type_traits>
+
 #define ANSX_PA_SLOTS 20480u  // hash set capacity: >= 1.25 x 16384 values per block
 #define ANSX_PA_EMPTY 0xFFFFFFFFu
 #define ANSX_PA_MAX_BLOCK 16384u
@@ -69,26 +71,67 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
     __syncthreads();
     const u32 sigma = sh_cnt;
     if (tid == 0 && sh_max >= value_limit) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
-    // sort the distinct values (bitonic, padded to a power of two)
-    u32 N2 = 2;
+    // sort the distinct values (bitonic, padded to a power of two).  Every thread keeps E = N2 / 1024 consecutive
+    // elements in registers: a stage whose partner distance is below E is a compare-exchange inside the thread, below
+    // 64 E a shuffle inside the wave, and only the others (10 of the 78 stages at N2 = 4096) go through LDS and a
+    // barrier -- with every stage through LDS the sort was half of this kernel's time.
+    u32 N2 = 1024;
     while (N2 < sigma) N2 <<= 1;
     for (u32 i = sigma + tid; i < N2; i += nt) uq[i] = 0xFFFFFFFFu;
     __syncthreads();
-    for (u32 k = 2; k <= N2; k <<= 1) {
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < N2; i += nt) {
-                const u32 ixj = i ^ j;
-                if (ixj > i) {
-                    const bool asc = (i & k) == 0;
-                    const u32 x = uq[i], y = uq[ixj];
-                    if ((x > y) == asc) {
-                        uq[i] = y;
-                        uq[ixj] = x;
+    auto sort_regs = [&](auto tag) {
+        constexpr u32 E = decltype(tag)::value;
+        u32 r[E];
+#pragma unroll
+        for (u32 e = 0; e < E; e++) r[e] = uq[tid * E + e];
+        for (u32 k = 2; k <= N2; k <<= 1) {
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64 * E) {  // partner in another wave
+                    __syncthreads();
+#pragma unroll
+                    for (u32 e = 0; e < E; e++) uq[tid * E + e] = r[e];
+                    __syncthreads();
+#pragma unroll
+                    for (u32 e = 0; e < E; e++) {
+                        const u32 i = tid * E + e;
+                        const u32 o = uq[i ^ j];
+                        const bool keep_min = ((i & k) == 0) == ((i & j) == 0);
+                        r[e] = keep_min ? (r[e] < o ? r[e] : o) : (r[e] < o ? o : r[e]);
+                    }
+                } else if (j >= E) {  // partner in another lane of this wave, same register
+#pragma unroll
+                    for (u32 e = 0; e < E; e++) {
+                        const u32 i = tid * E + e;
+                        const u32 o = (u32)__shfl_xor((int)r[e], (int)(j / E));
+                        const bool keep_min = ((i & k) == 0) == ((i & j) == 0);
+                        r[e] = keep_min ? (r[e] < o ? r[e] : o) : (r[e] < o ? o : r[e]);
+                    }
+                } else {  // partner in this thread
+#pragma unroll
+                    for (u32 e = 0; e < E; e++) {
+                        if ((e & j) == 0) {
+                            const u32 i = tid * E + e;
+                            const u32 x = r[e], y = r[e | j];
+                            const bool asc = (i & k) == 0;
+                            const bool swap = (x > y) == asc;
+                            r[e] = swap ? y : x;
+                            r[e | j] = swap ? x : y;
+                        }
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+#pragma unroll
+        for (u32 e = 0; e < E; e++) uq[tid * E + e] = r[e];
+        __syncthreads();
+    };
+    switch (N2 / 1024) {
+    case 1: sort_regs(std::integral_constant<u32, 1>{}); break;
+    case 2: sort_regs(std::integral_constant<u32, 2>{}); break;
+    case 4: sort_regs(std::integral_constant<u32, 4>{}); break;
+    case 8: sort_regs(std::integral_constant<u32, 8>{}); break;
+    default: sort_regs(std::integral_constant<u32, 16>{}); break;
     }
     // running sums of the alphabet (pseudo_adaptive.cpp:103-105, u32 there: the exact sum must fit)
     {
@@ -108,19 +151,23 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
             blk[b].pa_sigma = sigma;
         }
     }
-    // 1-based rank of every value (:91-103)
+    // 1-based rank of every value (:91-103): branch-free lower bound over the padded, sorted array (the padding
+    // compares above every value), the thread's 16 searches advancing together -- 16 independent LDS reads per step
+    __syncthreads();
+    {
+        u32 lo[PA_VPT];
 #pragma unroll
-    for (u32 q = 0; q < PA_VPT; q++) {
-        const u32 i = tid + q * nt;
-        if (i >= nb) break;
-        const u32 v = vals[q];
-        u32 lo = 0, hi = sigma;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (uq[mid] < v) lo = mid + 1;
-            else hi = mid;
+        for (u32 q = 0; q < PA_VPT; q++) lo[q] = 0;
+        for (u32 st = N2 >> 1; st > 0; st >>= 1) {
+            u32 probe[PA_VPT];
+#pragma unroll
+            for (u32 q = 0; q < PA_VPT; q++) probe[q] = uq[lo[q] + st - 1];
+#pragma unroll
+            for (u32 q = 0; q < PA_VPT; q++) lo[q] += probe[q] < vals[q] ? st : 0u;
         }
-        dst[i] = lo + 1;
+#pragma unroll
+        for (u32 q = 0; q < PA_VPT; q++)
+            if (tid + q * nt < nb) dst[tid + q * nt] = lo[q] + 1;
     }
 }
 

@@ -197,6 +197,8 @@ __global__ __launch_bounds__(64) void k_pa_parse(const u8* __restrict__ cont, an
 {
     __shared__ uint4 stkA[24][64];  // pending right subtrees: (a, n) and the bounds as two 64-bit halves
     __shared__ uint2 stkB[24][64];
+    constexpr u32 PA_WIN = 64;      // window words per lane
+    __shared__ u32 win[PA_WIN][64];
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x * 64 + lane;
     if (b >= g.nblocks) return;
@@ -214,15 +216,37 @@ __global__ __launch_bounds__(64) void k_pa_parse(const u8* __restrict__ cont, an
         const u8* bp = stream + 8;
         const u64 maxbits = (u64)(sbytes - 8) * 8;
         u64 bitpos = 0;
-        auto getbits = [&](u32 nbits) -> u32 {  // nbits in [0, 32]; never reads past the block's bytes
+        // The code is read strictly front to back: every lane keeps the next 256 bytes of its header in its own
+        // column of an LDS window; when any lane of the wave is about to run out, ALL lanes refill theirs from
+        // where they stand, with 64 independent loads each (one global round trip per ~100 items for the whole
+        // wave; an 8-byte global load per item, each waiting on the position the previous one produced, made this
+        // kernel 3.3 ms, and lanes refilling one by one 6.3).  Bytes past the block's own are never read and
+        // count as zero.
+        const u32 nbytes = sbytes - 8;
+        u64 wbit0 = 0;
+        auto refill = [&]() {
+            wbit0 = bitpos & ~31ull;
+            const u32 byte0 = (u32)(wbit0 >> 3);
+            if (byte0 + 4 * PA_WIN <= nbytes) {
+#pragma unroll
+                for (u32 k = 0; k < PA_WIN; k++) win[k][lane] = ld_u32_unaligned(bp + byte0 + 4 * k);
+            } else {
+                for (u32 k = 0; k < PA_WIN; k++) {
+                    const u32 off = byte0 + 4 * k;
+                    u32 v = 0;
+                    for (u32 i = 0; i < 4 && off + i < nbytes; i++) v |= (u32)bp[off + i] << (8 * i);
+                    win[k][lane] = v;
+                }
+            }
+            wave_lds_sync();
+        };
+        refill();
+        auto getbits = [&](u32 nbits) -> u32 {  // nbits in [0, 32]; the caller keeps 96 bits of window ahead
             if (nbits == 0) return 0u;
-            const u64 byte = bitpos >> 3;
-            u64 w = 0;
-            const u64 avail = (u64)(sbytes - 8) - byte;
-            if (avail >= 8) w = ld_u64_unaligned(bp + byte);
-            else
-                for (u64 i = 0; i < avail; i++) w |= (u64)bp[byte + i] << (8 * i);
-            const u32 v = (u32)((w >> (bitpos & 7)) & (nbits >= 32 ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
+            const u32 rel = (u32)(bitpos - wbit0);
+            const u32 word = rel >> 5;
+            const u64 w = (u64)win[word][lane] | ((u64)win[word + 1][lane] << 32);
+            const u32 v = (u32)((w >> (rel & 31u)) & (nbits >= 32 ? 0xFFFFFFFFull : ((1ull << nbits) - 1ull)));
             bitpos += nbits;
             return v;
         };
@@ -231,6 +255,8 @@ __global__ __launch_bounds__(64) void k_pa_parse(const u8* __restrict__ cont, an
         u64 prev_sum = 0;  // values come out in index order only within a subtree: differences are taken afterwards
         (void)prev_sum;
         for (u32 it = 0; it < sigma && !err; it++) {
+            // (an item reads at most 33 bits; 96 keeps word + 1 inside the window)
+            if (__any((u32)(bitpos - wbit0) + 96 > PA_WIN * 32)) refill();
             if (n == 0) {
                 if (sp == 0) {
                     err = 1;
@@ -276,11 +302,18 @@ __global__ __launch_bounds__(64) void k_pa_parse(const u8* __restrict__ cont, an
         if (hb > sbytes) err = 1;
         if (!err) {  // running sums -> values (this lane wrote every entry itself)
             u32 prev = 0;
-            for (u32 j = 0; j < sigma; j++) {
-                const u32 cur = out[j];
-                if (j && cur <= prev) err = 1;  // distinct ascending values: sums strictly increase (value 0 only first)
-                out[j] = cur - prev;
-                prev = cur;
+            for (u32 j0 = 0; j0 < sigma; j0 += 16) {  // 16 independent loads per round trip
+                u32 cur[16];
+#pragma unroll
+                for (u32 u = 0; u < 16; u++) cur[u] = j0 + u < sigma ? out[j0 + u] : 0u;
+#pragma unroll
+                for (u32 u = 0; u < 16; u++) {
+                    if (j0 + u < sigma) {
+                        if ((j0 + u) && cur[u] <= prev) err = 1;  // distinct ascending values: sums strictly increase (value 0 only first)
+                        out[j0 + u] = cur[u] - prev;
+                        prev = cur[u];
+                    }
+                }
             }
         }
     }
@@ -305,7 +338,42 @@ __global__ __launch_bounds__(256) void k_pa_unmap(ansx_geo g, const u32* __restr
         for (u32 i = threadIdx.x; i < nb; i += 256) o[i] = v;
         return;
     }
-    for (u32 i = threadIdx.x; i < nb; i += 256) {
+    // 16 ranks per thread and round are requested together, then their 16 values: two round trips per round
+    // instead of two per int (the kernel was a chain of 128 dependent round trips per block)
+    u32 done = 0;
+    if ((((uintptr_t)o) & 15u) == 0) {
+        uint4* o4 = (uint4*)o;
+        const u32 nvec = nb >> 2;
+        for (u32 v0 = 0; v0 < nvec; v0 += 4 * 256) {
+            uint4 r4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 v = v0 + j * 256 + threadIdx.x;
+                r4[j] = v < nvec ? o4[v] : make_uint4(1u, 1u, 1u, 1u);
+            }
+            u32 r[16], x[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[4 * j] = r4[j].x, r[4 * j + 1] = r4[j].y, r[4 * j + 2] = r4[j].z, r[4 * j + 3] = r4[j].w;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const bool ok = r[j] >= 1 && r[j] <= sigma;
+                bad |= ok ? 0u : 1u;
+                x[j] = al[ok ? r[j] - 1 : 0u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 v = v0 + j * 256 + threadIdx.x;
+                // (a rank out of range: the int is left as decoded, as before, and the call fails with ERR_FORMAT)
+                const bool a0 = r[4 * j] >= 1 && r[4 * j] <= sigma, a1 = r[4 * j + 1] >= 1 && r[4 * j + 1] <= sigma;
+                const bool a2 = r[4 * j + 2] >= 1 && r[4 * j + 2] <= sigma, a3 = r[4 * j + 3] >= 1 && r[4 * j + 3] <= sigma;
+                if (v < nvec)
+                    o4[v] = make_uint4(a0 ? x[4 * j] : r[4 * j], a1 ? x[4 * j + 1] : r[4 * j + 1], a2 ? x[4 * j + 2] : r[4 * j + 2],
+                        a3 ? x[4 * j + 3] : r[4 * j + 3]);
+            }
+        }
+        done = nvec << 2;
+    }
+    for (u32 i = done + threadIdx.x; i < nb; i += 256) {
         const u32 r = o[i];
         if (r < 1 || r > sigma) bad = 1;
         else o[i] = al[r - 1];

@@ -54,6 +54,7 @@ struct ansx_ctx {
     std::map<u64, u32> ns_hint;
     std::map<u64, u32> rf_hint;  // rfold: most distinct values per block seen per geometry (optimistic hash-table size)
     u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
+    u32 cur_pa_distinct = 0;     // the same for the compaction layer's k_pa_remap (the hint itself)
     ansx_encode_stats last = {};
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
@@ -359,10 +360,27 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         // scratch slot, the codec then runs on the 1-based ranks
         if ((rc = ensure(c, c->mapped, (size_t)NB * g.block_ints * 4))) return rc;
         if ((rc = ensure(c, c->pa_alpha, (size_t)NB * g.block_ints * 4))) return rc;
-        const size_t lds1 = ((size_t)ANSX_PA_SLOTS + ANSX_PA_MAX_BLOCK) * 4;
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, (u32*)c->mapped.p, (u32*)c->pa_alpha.p, blk, gflags,
-            1u << 30);
+        // sizes from the geometry's distinct-value hint (optimistic calls only): hash set 2.5 x, value list the next
+        // power of two above 1.25 x; both workgroups of a CU must fit its LDS
+        u32 pa_slots = ANSX_PA_SLOTS, pa_uqcap = ANSX_PA_MAX_BLOCK;
+        bool pa_small = false;
+        if (optimistic && c->cur_pa_distinct != 0) {
+            const u32 d = c->cur_pa_distinct;
+            const u32 sl = (2 * d + d / 2 + 64 + 255) & ~255u;
+            u32 uc = 1024;
+            while (uc < d + d / 4 + 16) uc <<= 1;
+            if (((size_t)sl + uc) * 4 <= 78 * 1024 && uc <= ANSX_PA_MAX_BLOCK) pa_slots = sl, pa_uqcap = uc, pa_small = true;
+        }
+        const size_t lds1 = ((size_t)pa_slots + pa_uqcap) * 4;
+        if (pa_small) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            LAUNCH(c, "k_pa_remap", k_pa_remap2, NB, 1024, lds1, s, d_in, g, pa_slots, pa_uqcap, (u32*)c->mapped.p,
+                (u32*)c->pa_alpha.p, blk, gflags, 1u << 30);
+        } else {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, pa_slots, pa_uqcap, (u32*)c->mapped.p,
+                (u32*)c->pa_alpha.p, blk, gflags, 1u << 30);
+        }
         const size_t lds2 = ((size_t)2 * ANSX_PA_MAX_BLOCK + 16) * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_header, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         LAUNCH(c, "k_pa_header", k_pa_header, NB, 256, lds2, s, g, (const u32*)c->pa_alpha.p, blk, (u8*)c->scratch.p,
@@ -680,6 +698,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         && !c->dbg.model_sync;  // (with compaction too: the hint then describes the alphabets of the rank-remapped blocks)
     const auto rit = c->rf_hint.find(key);
     c->cur_rf_slots = (eligible && P.g.kind == ANSX_RFOLD && rit != c->rf_hint.end()) ? rf_opt_slots(rit->second, fold_T(P.g.f)) : 0u;
+    c->cur_pa_distinct = (eligible && P.g.pa && rit != c->rf_hint.end()) ? rit->second : 0u;
     if (eligible) {
         u32 ns_cap = (hint + 7u) & ~7u;
         if (ns_cap < 64) ns_cap = 64;
@@ -696,6 +715,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     if (rc == ANSX_RETRY_GENERAL) {
         missed = eligible;
         c->cur_rf_slots = 0;
+        c->cur_pa_distinct = 0;
         path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
@@ -709,7 +729,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         const u32 want = missed ? seen + seen / 8 + 8 : seen;
         u32& h = c->ns_hint[key];
         if (want > h) h = want;
-        if (P.g.kind == ANSX_RFOLD) {
+        if (P.g.kind == ANSX_RFOLD || P.g.pa) {
             const u32 d = c->h_pin[ANSX_G_RFDIST];
             u32& r = c->rf_hint[key];
             const u32 wantd = missed ? d + d / 8 + 8 : d;

@@ -24,26 +24,32 @@
 #define ANSX_PA_EMPTY 0xFFFFFFFFu
 #define ANSX_PA_MAX_BLOCK 16384u
 
-__device__ __forceinline__ u32 pa_slot(u32 v) { return (u32)(((u64)(v * 2654435761u) * ANSX_PA_SLOTS) >> 32); }
+__device__ __forceinline__ u32 pa_slot(u32 v, u32 slots) { return (u32)(((u64)(v * 2654435761u) * slots) >> 32); }
 
-// One workgroup of 1024 threads per block.  LDS: hash set (80 KB) + distinct values (64 KB).
-__global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, ansx_geo g, u32* __restrict__ mapped,
-    u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
+// One workgroup of 1024 threads per block.  LDS: hash set + distinct values: 80 + 64 KB for any block of 16 Ki ints
+// (slots = ANSX_PA_SLOTS, uqcap = ANSX_PA_MAX_BLOCK: the first call of a geometry), or sized from the most distinct
+// values a block of the geometry had so far (as k_rfold_remap_hash: two workgroups per CU on the 64-register build
+// k_pa_remap2; a block that does not fit raises the violation flag, leaves a valid one-value block, and the call is
+// repeated with the full sizes).
+__device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const ansx_geo& g, u32 slots, u32 uqcap,
+    u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags,
+    u32 value_limit)
 {
     extern __shared__ u32 pa_lds[];
-    __shared__ u32 sh_cnt, sh_max;
+    __shared__ u32 sh_cnt, sh_max, sh_ovf;
     __shared__ u64 sh_part64[20];
-    u32* keys = pa_lds;                  // [SLOTS]
-    u32* uq = pa_lds + ANSX_PA_SLOTS;    // [16384] distinct values
+    u32* keys = pa_lds;                  // [slots]
+    u32* uq = pa_lds + slots;            // [uqcap] distinct values (uqcap: a power of two >= 1024)
     const u32 tid = threadIdx.x, nt = 1024;
     const u32 b = blockIdx.x;
     const u32 nb = geo_block_n(g, b);
     const u32* src = in + (u64)b * g.block_ints;
     u32* dst = mapped + (u64)b * g.block_ints;
-    for (u32 i = tid; i < ANSX_PA_SLOTS; i += nt) keys[i] = ANSX_PA_EMPTY;
+    for (u32 i = tid; i < slots; i += nt) keys[i] = ANSX_PA_EMPTY;
     if (tid == 0) {
         sh_cnt = 0;
         sh_max = 0;
+        sh_ovf = 0;
     }
     __syncthreads();
     // distinct values: first inserter of a value appends it to uq.  A thread's 16 values (blocks hold at most
@@ -59,18 +65,34 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
         if (tid + q * nt >= nb) break;
         const u32 v = vals[q];
         lmax = v > lmax ? v : lmax;
-        u32 slot = pa_slot(v);
-        for (u32 probes = 0; probes < ANSX_PA_SLOTS; probes++) {
+        u32 slot = pa_slot(v, slots);
+        u32 probes = 0;
+        for (; probes < slots; probes++) {
             const u32 old = atomicCAS(&keys[slot], ANSX_PA_EMPTY, v);
-            if (old == ANSX_PA_EMPTY) uq[atomicAdd(&sh_cnt, 1u)] = v;
+            if (old == ANSX_PA_EMPTY) {
+                const u32 at = atomicAdd(&sh_cnt, 1u);
+                if (at < uqcap) uq[at] = v;
+            }
             if (old == ANSX_PA_EMPTY || old == v) break;
-            slot = slot + 1 == ANSX_PA_SLOTS ? 0 : slot + 1;
+            slot = slot + 1 == slots ? 0 : slot + 1;
         }
+        if (probes == slots) sh_ovf = 1;  // table full (only possible below the full size)
     }
     atomicMax(&sh_max, lmax);
     __syncthreads();
+    if (sh_ovf || sh_cnt > uqcap) {  // optimistic sizes too small: a valid one-value block, and the call is repeated
+        for (u32 i = tid; i < nb; i += nt) dst[i] = 1;
+        if (tid == 0) {
+            alpha_sum[(u64)b * g.block_ints] = 0;
+            blk[b].pa_sigma = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_VIOL_BIT);
+            atomicMax(&gflags[ANSX_G_RFDIST], sh_cnt > slots ? sh_cnt : slots);
+        }
+        return;
+    }
     const u32 sigma = sh_cnt;
     if (tid == 0 && sh_max >= value_limit) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
+    if (tid == 0 && sigma > gflags[ANSX_G_RFDIST]) atomicMax(&gflags[ANSX_G_RFDIST], sigma);
     // sort the distinct values (bitonic, padded to a power of two).  Every thread keeps E = N2 / 1024 consecutive
     // elements in registers: a stage whose partner distance is below E is a compare-exchange inside the thread, below
     // 64 E a shuffle inside the wave, and only the others (10 of the 78 stages at N2 = 4096) go through LDS and a
@@ -169,6 +191,18 @@ __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, a
         for (u32 q = 0; q < PA_VPT; q++)
             if (tid + q * nt < nb) dst[tid + q * nt] = lo[q] + 1;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, ansx_geo g, u32 slots, u32 uqcap,
+    u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
+{
+    pa_remap_body(in, g, slots, uqcap, mapped, alpha_sum, blk, gflags, value_limit);
+}
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pa_remap2(const u32* __restrict__ in,
+    ansx_geo g, u32 slots, u32 uqcap, u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk,
+    u32* __restrict__ gflags, u32 value_limit)
+{
+    pa_remap_body(in, g, slots, uqcap, mapped, alpha_sum, blk, gflags, value_limit);
 }
 
 // Alphabet header: one workgroup of 256 threads per block (the prelude writer's generic path).

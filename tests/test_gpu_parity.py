@@ -166,6 +166,29 @@ def test_rfold_optimistic_hash_table(A, oracle_built):
     assert np.array_equal(codec.encode(few), first)
 
 
+def test_compaction_optimistic_hash_set(A, oracle_built):
+    """The compaction layer's remap kernel sizes its hash set and value list like the ANSrfold remap: from the most
+    distinct values a block of the geometry had so far.  Same bytes as with the full sizes; blocks with more
+    distinct values than that overflow, and the call repeats itself with the full sizes (stats.path & 16)."""
+    own = A.Context(0)
+    n = 5 * 16384 + 777
+    few = ol.gen_inputs("zipf20s1.2", n, seed=5)
+    many = np.random.default_rng(6).integers(0, 1 << 15, size=n, dtype=np.uint32)  # ~13 K distinct values per block
+                                                                                   # (their sum stays below 2^32)
+    codec = A.ANSfold(1, ctx=own, block_ints=16384, ckpt_interval=1024, compact=True)
+    first = codec.encode(few)                            # discovery: full sizes
+    assert np.array_equal(codec.decode(first, n), few)
+    second = codec.encode(few)                           # optimistic: small sizes
+    assert own.last_encode_stats()["path"] & 16 == 0
+    assert np.array_equal(first, second)
+    cont = codec.encode(many)                            # overflows them
+    assert own.last_encode_stats()["path"] & 16
+    assert np.array_equal(codec.decode(cont, n), many)
+    fresh = A.ANSfold(1, ctx=A.Context(0), block_ints=16384, ckpt_interval=1024, compact=True)
+    assert np.array_equal(fresh.encode(many), cont)      # equal to a discovery-path encode
+    assert np.array_equal(codec.encode(few), first)
+
+
 @pytest.mark.parametrize("kind", [ol.FOLD, ol.RFOLD])
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 313, 1000, 1001, 4096, 4097])
 def test_small_and_ragged_sizes(A, ctx, kind, n):

@@ -172,8 +172,11 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             where the two could decide differently.  Expected to be 0, always; a non-zero
  *                             value marks an output whose bit-parity with the reference is not guaranteed.
  *   path                      0 discovery (alphabet size read back mid-call), 1 launched back to back on the
- *                             context's alphabet hint, 2 the same with the fused model kernel; + 16: the hint
- *                             did not hold and the call was repeated on the discovery path */
+ *                             context's hints for this geometry (largest alphabet; for ANSrfold and the
+ *                             compaction layer also the most distinct values a block had, which sizes their
+ *                             per-block hash tables), 2 the same with the fused model kernel; + 16: a hint
+ *                             did not hold and the call was repeated on the discovery path.  Either way the
+ *                             output bytes are the same. */
 typedef struct {
     uint32_t max_nsyms;
     uint32_t max_log2_frame;

@@ -381,10 +381,10 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, pa_slots, pa_uqcap, (u32*)c->mapped.p,
                 (u32*)c->pa_alpha.p, blk, gflags, 1u << 30);
         }
-        const size_t lds2 = ((size_t)2 * ANSX_PA_MAX_BLOCK + 16) * 4;
+        const size_t lds2 = pa_small ? ((size_t)3 * pa_uqcap + 32) * 4 : ((size_t)2 * ANSX_PA_MAX_BLOCK + 16) * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_header, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         LAUNCH(c, "k_pa_header", k_pa_header, NB, 256, lds2, s, g, (const u32*)c->pa_alpha.p, blk, (u8*)c->scratch.p,
-            (u64)scr_stride);
+            (u64)scr_stride, pa_small ? pa_uqcap : (u32)ANSX_PA_MAX_BLOCK);
         src = (const u32*)c->mapped.p;
     }
     // K1

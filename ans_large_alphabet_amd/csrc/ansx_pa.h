@@ -205,9 +205,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     pa_remap_body(in, g, slots, uqcap, mapped, alpha_sum, blk, gflags, value_limit);
 }
 
-// Alphabet header: one workgroup of 256 threads per block (the prelude writer's generic path).
+// Alphabet header: one workgroup of 256 threads per block (the prelude writer's generic path).  `cap` = words per
+// LDS array: ANSX_PA_MAX_BLOCK (offsets + bit buffer = 128 KB: one workgroup per CU, the running sums read from
+// HBM), or the value-list capacity k_pa_remap ran with on an optimistic call (a few thousand: three arrays --
+// the running sums are staged too -- and three workgroups per CU; a block k_pa_remap gave up on has sigma = 1).
 __global__ __launch_bounds__(256) void k_pa_header(ansx_geo g, const u32* __restrict__ alpha_sum,
-    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride)
+    ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, u32 cap)
 {
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
@@ -216,10 +219,20 @@ __global__ __launch_bounds__(256) void k_pa_header(ansx_geo g, const u32* __rest
     ansx_blk* B = &blk[b];
     const u32 sigma = B->pa_sigma;
     const u32* as = alpha_sum + (u64)b * g.block_ints;
-    u32* off = lds32;                          // [sigma]
-    u32* bits = lds32 + ANSX_PA_MAX_BLOCK;     // bit buffer
-    const u64 uni = (u64)as[sigma - 1] + 1;    // block_alphabet.back() + 1 (:108)
-    prelude_emit<0, true>(g, B, sigma, 0, as, off, bits, sh_part, scratch + (u64)b * scr_stride, nullptr, b, tid, uni);
+    u32* off = lds32;           // [sigma]
+    u32* bits = lds32 + cap;    // bit buffer (the code of sigma ascending values below 2^32 takes at most sigma words)
+    const u32* inc = as;
+    if (cap < ANSX_PA_MAX_BLOCK) {
+        u32* inc_lds = lds32 + 2 * cap + 16;
+        for (u32 i = tid; i < sigma; i += 256) inc_lds[i] = as[i];
+        __syncthreads();
+        inc = inc_lds;
+    }
+    const u64 uni = (u64)inc[sigma - 1] + 1;    // block_alphabet.back() + 1 (:108)
+    if (cap <= 4096)  // at most 16 items per thread: the writer's register-resident form
+        prelude_emit<16, true>(g, B, sigma, 0, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, nullptr, b, tid, uni);
+    else
+        prelude_emit<0, true>(g, B, sigma, 0, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, nullptr, b, tid, uni);
 }
 
 // Decoder side: alphabet header -> distinct values, one lane per block (serial bit parsing; values and the

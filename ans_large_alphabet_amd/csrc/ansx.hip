@@ -453,20 +453,24 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (const u32*)c->tab32.p, (ansx_enc_entry*)c->table.p);
     // K3 (also fills the container's parse hints)
     u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
+    // LDS arrays of the prelude writer: as long as the call's largest alphabet (known here on the discovery path,
+    // assumed = the hint on the optimistic one), not as its slot count
+    u32 pre_cap = optimistic ? ns_cap : max_ns;
+    pre_cap = std::min<u32>(NSP, std::max<u32>(64u, (pre_cap + 7u) & ~7u));
     if (NSP <= 1024 && max_logM <= 16) {
-        LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints);
+            (u64)scr_stride, mostfreq, hints, pre_cap);
     } else if (NSP <= 4096 && max_logM <= 16) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)((size_t)NSP * 12 + 64)));
-        LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)NSP * 12 + 64, s, g, NSP,
+                      (int)((size_t)pre_cap * 12 + 64)));
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints);
+            (u64)scr_stride, mostfreq, hints, pre_cap);
     } else {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints);
+            (u64)scr_stride, mostfreq, hints, NSP);
     }
     // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
     // alphabet / frame actually produced, read back above).

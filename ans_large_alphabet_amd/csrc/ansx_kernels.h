@@ -1042,8 +1042,11 @@ template <int IPT>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ hints)
+    u32* __restrict__ hints, u32 cap)
 {
+    // cap = words per LDS array: NSP, or on an optimistic call the alphabet hint the whole call is sized for (a
+    // 2300-symbol alphabet then takes 28 KB instead of the 48 KB of its 4096 slots: 5 instead of 3 workgroups per
+    // CU); a block above it writes nothing -- the call is repeated anyway (ANSX_G_MAXNSYMS > hint).
     constexpr bool SMALL = IPT > 0;
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
@@ -1065,9 +1068,13 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     }
     const u32 ns = B->max_sym + 1;
     const u32 logM = B->logM;
+    if (ns > cap) {
+        if (tid == 0) B->prelude_bytes = 0;
+        return;
+    }
     u32* off = lds32;         // [ns]
-    u32* bits = lds32 + NSP;  // bit buffer
-    u32* inc = SMALL ? lds32 + 2 * NSP : incbuf + (u64)b * NSP;
+    u32* bits = lds32 + cap;  // bit buffer
+    u32* inc = SMALL ? lds32 + 2 * cap : incbuf + (u64)b * NSP;
     if (SMALL) {
 #pragma unroll
         for (u32 r = 0; r < 4; r++) {

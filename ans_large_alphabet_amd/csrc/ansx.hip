@@ -407,7 +407,9 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         NSP, hist, hterm, h_in_hist ? 1u : 0u, blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
-    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)NSP * 4 + (h_deferred ? 0 : 512 * 8);
+    // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)
+    const u32 sort_cap = (optimistic && h_deferred) ? std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 7u) & ~7u)) : NSP;
+    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)sort_cap * 4 + (h_deferred ? 0 : 512 * 8);
     if (k2a_lds > 32 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
@@ -415,7 +417,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
-        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk);
+        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch
     // needs anyway (largest alphabet / frame), so further batches are launched only on demand.

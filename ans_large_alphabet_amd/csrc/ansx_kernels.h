@@ -248,9 +248,12 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 // drain every outstanding global store (vmcnt(0)) at each call.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// cap = entries of the staged histogram row: NSP, or the alphabet hint on an optimistic call (this one-wave-per-block
+// kernel is bound by how many blocks a CU's LDS holds: 2300-symbol alphabets, 28 -> 21 KB per block).  A block
+// above the hint is left as the call's memset made it -- no model, no stream -- and the call is repeated.
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
-    ansx_blk* __restrict__ blk)
+    ansx_blk* __restrict__ blk, u32 cap)
 {
     extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
     __shared__ u32 cnt[ANSX_VMAX];
@@ -258,8 +261,8 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     __shared__ unsigned long long vmask[ANSX_MASKV];  // lanes of the current pass per frequency value
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
-    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [NSP] this block's histogram row
-    double* terms = (double*)(hrow + NSP);   // [512], only allocated when the entropy is summed here
+    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [cap] this block's histogram row
+    double* terms = (double*)(hrow + cap);   // [512], only allocated when the entropy is summed here
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const u32* h = hist + (u64)b * NSP;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 #pragma unroll
     for (u32 r = 0; r < SORT_PRE; r++) hp[r] = r * 64 + lane < NSP ? h[r * 64 + lane] : 0u;
     const u32 ns = blk[b].max_sym + 1;
+    if (ns > cap) return;
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
 #pragma unroll

@@ -16,6 +16,7 @@
 #include "ansx_kernels.h"
 #include "ansx_rfold.h"
 #include "ansx_model.h"
+#include "ansx_fastmodel.h"
 #include "ansx_gen.h"
 #include "ansx_pa.h"
 
@@ -47,12 +48,15 @@ struct ansx_ctx {
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info;
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
     std::map<u64, u32> ns_hint;
     std::map<u64, u32> rf_hint;  // rfold: most distinct values per block seen per geometry (optimistic hash-table size)
+    std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
+    bool used_fast = false;      // set by encode_general: the call's model came from k_candidates / k_model_finish
+    u32 cur_nt = 0;              // set by encode_dev: candidates per block for the fast model path of this call (0 = exact path)
     u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
     u32 cur_pa_distinct = 0;     // the same for the compaction layer's k_pa_remap (the hint itself)
     ansx_encode_stats last = {};
@@ -72,6 +76,9 @@ struct ansx_ctx {
         bool model_fused = false;     // ANSX_MODEL_FUSED: the single LDS-resident model kernel instead of the five tailored ones
         bool model_sync = false;      // ANSX_MODEL_SYNC: always discover the alphabet with the mid-call read-back
         u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
+        u32 t_hint = 0;               // ANSX_T_HINT: candidates per block for every call (0 = learn per geometry)
+        bool no_fast_model = false;   // ANSX_NO_FAST_MODEL: optimistic calls keep the exact model kernels
+        double fast_guard = ANSX_FAST_GUARD;  // ANSX_FAST_GUARD: relative guard band of the fast model path's stop rule (tests widen it)
     } dbg;
 };
 
@@ -398,13 +405,26 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // entropy terms are evaluated by the histogram kernel when it sees whole blocks; alphabets up
     // to 2048 slots are also summed there (terms in LDS), larger ones through HBM in K2b
     const bool h_in_hist = h_deferred && NSP <= 2048;
+    // Fast model path (ansx_fastmodel.h): geometries seen before, whole-block histograms, 16-bit frequencies,
+    // compact tables; every assumption is checked on the device and a miss repeats the call on the exact path.
+    const u32 NT = optimistic ? c->cur_nt : 0u;
+    const bool fast = NT != 0 && !g.pa && h_deferred && g.block_ints <= 65535u && NSP <= 4096 && !c->dbg.table16_fixup
+        && !c->dbg.encode_gtab16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
+    c->used_fast = fast;
+    if (fast) {
+        if ((rc = ensure(c, c->pairs, (size_t)NB * NSP * 8))) return rc;
+        if (!c->lg2i.p) {  // log2 of the integers below 2^16, once per context (512 KB)
+            if ((rc = ensure(c, c->lg2i, (size_t)65536 * 8))) return rc;
+            LAUNCH(c, "k_build_log2i_lut", k_build_log2i_lut, 256, 256, 0, s, (double*)c->lg2i.p);
+        }
+    }
     double* hterm = nullptr;
-    if (h_deferred && !h_in_hist) {
+    if (h_deferred && !h_in_hist && !fast) {
         if ((rc = ensure(c, c->hterm, (size_t)NB * NSP * 8))) return rc;
         hterm = (double*)c->hterm.p;
     }
     LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, h_in_hist ? (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (size_t)NSP * 8 + 80 : (size_t)NSP * 4, s, src, g, chunk, cpb,
-        NSP, hist, hterm, h_in_hist ? 1u : 0u, blk, gflags, 1u << 30);
+        NSP, hist, hterm, (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, 1u << 30);
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)
@@ -417,7 +437,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
-        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap);
+        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch
     // needs anyway (largest alphabet / frame), so further batches are launched only on demand.
@@ -428,7 +448,27 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // scratch slots too far apart for the f64 encoder's 31-bit buffer offsets)
     const bool test_fixup = c->dbg.table16_fixup;  // tests: integer-state encoder fed by k_table16_from32
     const u32 always16 = (!test_fixup && (NSP > 4096 || (u64)scr_stride * 16 >= 0x7FFFFF00ull || c->dbg.encode_gtab16)) ? 1u : 0u;
-    for (u32 batch = 0; batch < nbatch; batch++) {
+    u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
+    if (fast) {
+        const u32 bpw = 64u / NT;
+        const size_t cl = (size_t)bpw * ANSX_CAND_ROW * 16;
+        LAUNCH(c, "k_candidates", k_candidates, (NB + bpw - 1) / bpw, 64, cl, s, g, NSP, NT, (const uint2*)c->pairs.p,
+            (const ansx_blk*)blk, (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)c->lg2i.p);
+        const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
+        const size_t fl = (size_t)fcap * 12 + 64;
+        if (NSP <= 1024) {
+            LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const u32*)hist, (const u16*)c->attS.p,
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
+        } else {
+            if (fl > 48 * 1024)
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+            LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const u32*)hist, (const u16*)c->attS.p,
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
+        }
+        max_logM = 16;
+        max_ns = ns_cap;
+    }
+    for (u32 batch = 0; batch < (fast ? 0u : nbatch); batch++) {
         if (batch) HIPCHK(c, hipMemsetAsync(&gflags[ANSX_G_PAD], 0, 4, s));
         LAUNCH(c, "k_scale_attempts", k_scale_attempts, ((size_t)NB * ANSX_ATTEMPTS + 255) / 256, 256,
             0, s, g, NSP, batch, hist, (const u32*)c->sortF.p, (const u16*)c->sortSym.p, blk,
@@ -454,12 +494,13 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         LAUNCH(c, "k_table16_from32", k_table16_from32, NB, 256, 0, s, g, NSP, (const ansx_blk*)blk,
             (const u32*)c->tab32.p, (ansx_enc_entry*)c->table.p);
     // K3 (also fills the container's parse hints)
-    u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
     // LDS arrays of the prelude writer: as long as the call's largest alphabet (known here on the discovery path,
     // assumed = the hint on the optimistic one), not as its slot count
     u32 pre_cap = optimistic ? ns_cap : max_ns;
     pre_cap = std::min<u32>(NSP, std::max<u32>(64u, (pre_cap + 7u) & ~7u));
-    if (NSP <= 1024 && max_logM <= 16) {
+    if (fast) {
+        // (k_model_finish wrote the preludes)
+    } else if (NSP <= 1024 && max_logM <= 16) {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq, hints, pre_cap);
@@ -526,7 +567,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         (u64)scr_stride, d_out + P.lay.payload_off, gflags);
     if (!P.plain)
         LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (optimistic) {
         if (c->h_pin[ANSX_G_ERR] & (1u << 6)) return ANSX_ERR_DOMAIN;
@@ -705,6 +746,11 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
     const auto rit = c->rf_hint.find(key);
     c->cur_rf_slots = (eligible && P.g.kind == ANSX_RFOLD && rit != c->rf_hint.end()) ? rf_opt_slots(rit->second, fold_T(P.g.f)) : 0u;
     c->cur_pa_distinct = (eligible && P.g.pa && rit != c->rf_hint.end()) ? rit->second : 0u;
+    // candidates per block for the fast model path: one more than the largest index chosen so far, 4..8 lanes
+    // (fewer than 4 would leave the wave's lanes to more blocks than its LDS rows); above 8 the exact path stays
+    const auto tit = c->t_hint.find(key);
+    const u32 tcount = c->dbg.t_hint ? c->dbg.t_hint : (tit != c->t_hint.end() ? tit->second : 0u);
+    c->cur_nt = (eligible && !c->dbg.no_fast_model && tcount != 0 && tcount <= 8) ? std::max<u32>(4u, tcount) : 0u;
     if (eligible) {
         u32 ns_cap = (hint + 7u) & ~7u;
         if (ns_cap < 64) ns_cap = 64;
@@ -717,7 +763,7 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
             rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, ns_cap);
     }
     bool missed = false;
-    u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK && !P.g.pa ? 2u : 1u);
+    u32 path = !eligible ? 0u : (c->dbg.model_fused && P.g.block_ints <= ANSX_MODEL_MAX_BLOCK && !P.g.pa ? 2u : (c->used_fast ? 5u : 1u));
     if (rc == ANSX_RETRY_GENERAL) {
         missed = eligible;
         c->cur_rf_slots = 0;
@@ -735,6 +781,9 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         const u32 want = missed ? seen + seen / 8 + 8 : seen;
         u32& h = c->ns_hint[key];
         if (want > h) h = want;
+        u32& th = c->t_hint[key];
+        const u32 wantt = c->h_pin[ANSX_G_MAXT] + 1u + (missed ? 1u : 0u);
+        if (wantt > th) th = wantt;
         if (P.g.kind == ANSX_RFOLD || P.g.pa) {
             const u32 d = c->h_pin[ANSX_G_RFDIST];
             u32& r = c->rf_hint[key];
@@ -1082,7 +1131,7 @@ int ansx_init(int device, ansx_ctx** out)
         return ANSX_ERR_HIP;
     }
     static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN", "ANSX_PARSE_FAST",
-        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT" };
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
@@ -1113,6 +1162,9 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
         c->dbg.decode_mode = !value ? 0 : !strcmp(value, "ring") ? 1 : !strcmp(value, "staged") ? 2 : 0;
     else if (!strcmp(name, "ANSX_PARSE_STAGE_WORDS")) c->dbg.parse_stage_words = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NS_HINT")) c->dbg.ns_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
+    else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
+    else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
+    else if (!strcmp(name, "ANSX_FAST_GUARD")) c->dbg.fast_guard = (value && value[0]) ? strtod(value, nullptr) : ANSX_FAST_GUARD;
     else return ANSX_ERR_ARG;
     return ANSX_OK;
 }
@@ -1124,7 +1176,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {
@@ -1389,7 +1441,7 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
     if (!c) return 0;
     const DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info, &c->pairs };
     size_t t = 0;
     for (const DevBuf* b : bufs) t += b->cap;
     return t;

@@ -55,7 +55,8 @@ typedef u32 ansx_u32x4 __attribute__((ext_vector_type(4)));
 enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
     // (words 4, 5 hold the 64-bit payload size)
     ANSX_G_NEAR = 6,    // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
-    ANSX_G_RFDIST = 7 };  // rfold: the most distinct values any block of the call had (sizes the next call's hash tables)
+    ANSX_G_RFDIST = 7,  // rfold: the most distinct values any block of the call had (sizes the next call's hash tables)
+    ANSX_G_MAXT = 8 };  // largest chosen candidate index t (frame = M0 * 2^t) of the call: lanes per block of k_candidates
 
 // The one step of the path whose parity with the reference is empirical rather than by construction:
 // log2 is libm's there and ansx_log2_portable here (<= 1 ulp apart), so the decision XH < H * 1.001
@@ -84,9 +85,15 @@ __device__ __forceinline__ uint4 ld16_stream(const uint4* p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
-    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm, u32 sum_here,
+    u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm, u32 sum_mode,
     ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
 {
+    // sum_mode bit 0: four histogram copies, entropy terms kept in LDS (alphabets <= 2048 slots);
+    //          bit 1: the fast model path -- H is the workgroup's tree sum of the terms instead of the reference's
+    //                 left-to-right sum (within ~1e-13 of it; the stop rule of that path keeps a 1e-9 guard band
+    //                 around its threshold and sends anything closer to the exact path, see k_model_finish)
+    const u32 sum_here = sum_mode & 1u;
+    const bool tree_sum = (sum_mode & 2u) != 0;
     extern __shared__ u32 lds_hist[];
     const u32 tid = threadIdx.x;
     const u32 b = blockIdx.x / cpb, c = blockIdx.x % cpb;
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         // ones: the terms go to HBM and k_scale_attempts sums them.
         const double nd = (double)nb;
         double* lds_term = (double*)aux;
-        double* ht = sum_here ? nullptr : hterm + (u64)b * NSP;
+        double* ht = (sum_here || tree_sum) ? nullptr : hterm + (u64)b * NSP;
+        double part = 0.0;
         for (u32 s = tid; s < NSP; s += 256) {
             u32 fr = lds_hist[s];
             if (sum_here) fr += lds_hist[cstride + s] + lds_hist[2 * cstride + s] + lds_hist[3 * cstride + s];
@@ -178,10 +186,22 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
                 const double p = ansx_div_int31((double)fr, nd);
                 t = p * ansx_log2_portable(p);
             }
-            if (sum_here) lds_term[s] = t;
+            if (tree_sum) part = part + t;
+            else if (sum_here) lds_term[s] = t;
             else ht[s] = t;
         }
-        if (sum_here) {
+        if (tree_sum) {
+            for (int o = 32; o > 0; o >>= 1) part = part + __shfl_xor(part, o);
+            __syncthreads();  // every histogram word has been read: the first 4 doubles of the LDS are free
+            double* wpart = (double*)lds_hist;
+            if ((tid & 63) == 0) wpart[tid >> 6] = part;
+            __syncthreads();
+            if (tid == 0) {
+                const double H = -((wpart[0] + wpart[1]) + (wpart[2] + wpart[3]));
+                blk[b].H = H;
+                blk[b].thr = H * (1.0 + (double)1 / (double)1000);  // ans_util.hpp:124
+            }
+        } else if (sum_here) {
             // symbols above the block's largest one are absent (+0.0 terms): stop there
             u32 wmax = lmax;
             for (int o = 32; o > 0; o >>= 1) {
@@ -251,14 +271,18 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // cap = entries of the staged histogram row: NSP, or the alphabet hint on an optimistic call (this one-wave-per-block
 // kernel is bound by how many blocks a CU's LDS holds: 2300-symbol alphabets, 28 -> 21 KB per block).  A block
 // above the hint is left as the call's memset made it -- no model, no stream -- and the call is repeated.
+// pairs != nullptr (the fast model path, blocks of at most 65535 ints): instead of sortF / sortSym the kernel writes
+// one uint2 per rank: { freq | sym << 16, fs_rem } with fs_rem = n - (sum of the frequencies ranked before it),
+// the divisor of that symbol's scale_freqs step (ans_util.hpp:83), so that k_candidates can prepare its reciprocal.
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
-    ansx_blk* __restrict__ blk, u32 cap)
+    ansx_blk* __restrict__ blk, u32 cap, uint2* __restrict__ pairs)
 {
     extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
     __shared__ u32 cnt[ANSX_VMAX];
     __shared__ u16 cnt0[ANSX_VMAX];  // number of symbols per frequency value (before the scan)
     __shared__ unsigned long long vmask[ANSX_MASKV];  // lanes of the current pass per frequency value
+    __shared__ u32 wadj[ANSX_VMAX];  // packed output: (frequency mass ranked before the value's bin) - (bin start) * value
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
     u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [cap] this block's histogram row
@@ -276,6 +300,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     if (ns > cap) return;
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
+    uint2* oP = pairs ? pairs + (u64)b * NSP : nullptr;
 #pragma unroll
     for (u32 r = 0; r < SORT_PRE; r++)
         if (r * 64 + lane < ns) hrow[r * 64 + lane] = hp[r];
@@ -306,27 +331,47 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     }
     wave_lds_sync();
     // pass 2: exclusive scan of the bins -> first output position of every frequency value
-    u32 nsmall;
+    u32 nsmall, small_mass = 0;
     {
         const u32 per = ANSX_VMAX / 64;
-        u32 loc = 0;
-        for (u32 i = 0; i < per; i++) loc += cnt[lane * per + i];
-        u32 incl = loc;
+        u32 loc = 0, locw = 0;
+        for (u32 i = 0; i < per; i++) {
+            const u32 t = cnt[lane * per + i];
+            loc += t;
+            locw += t * (lane * per + i);
+        }
+        u32 incl = loc, inclw = locw;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            u32 t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
+            u32 t = __shfl_up(incl, d), tw = __shfl_up(inclw, d);
+            if ((int)lane >= d) {
+                incl += t;
+                inclw += tw;
+            }
         }
         nsmall = __shfl(incl, 63);
-        u32 run = incl - loc;
+        small_mass = __shfl(inclw, 63);  // sum of all frequencies below ANSX_VMAX
+        u32 run = incl - loc, runw = inclw - locw;
         for (u32 i = 0; i < per; i++) {
-            u32 t = cnt[lane * per + i];
-            cnt0[lane * per + i] = (u16)(t > 0xFFFFu ? 0xFFFFu : t);
-            cnt[lane * per + i] = run;
+            const u32 v = lane * per + i;
+            u32 t = cnt[v];
+            cnt0[v] = (u16)(t > 0xFFFFu ? 0xFFFFu : t);
+            cnt[v] = run;
+            wadj[v] = runw - run * v;  // (wrapping) mass before rank pos of value v = wadj[v] + pos * v
             run += t;
+            runw += t * v;
         }
     }
     wave_lds_sync();
+    const u32 ntot = (u32)total;
+    // one store per placed symbol: (frequency, symbol) as before, or the packed pair with the remaining mass
+    auto place = [&](u32 pos, u32 fr, u32 s) {
+        if (oP) oP[pos] = make_uint2((fr & 0xFFFFu) | (s << 16), ntot - (wadj[fr] + pos * fr));
+        else {
+            oF[pos] = fr;
+            oS[pos] = (u16)s;
+        }
+    };
     // pass 3: stable placement, 64 symbols at a time in index order
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
@@ -336,11 +381,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         // to the start of its bin (this covers nearly all "hot" symbols, whose values are all
         // distinct and would otherwise cost one loop iteration each)
         const bool uniq = small && cnt0[fr] == 1;
-        if (uniq) {
-            const u32 pos = cnt[fr];
-            oF[pos] = fr;
-            oS[pos] = (u16)s;
-        }
+        if (uniq) place(cnt[fr], fr, s);
         // Rank among the lanes of this pass that share a frequency value.  Values below
         // ANSX_MASKV (practically all that occur more than once): every lane ORs its lane bit
         // into the value's 64-bit LDS mask, reads the mask back, and its rank is the number of
@@ -353,9 +394,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         if (masked) {
             const unsigned long long m = vmask[fr];
             const unsigned long long below = m & ((1ull << lane) - 1ull);
-            const u32 pos = cnt[fr] + (u32)__popcll(below);
-            oF[pos] = fr;
-            oS[pos] = (u16)s;
+            place(cnt[fr] + (u32)__popcll(below), fr, s);
             if (below == 0) {
                 cnt[fr] += (u32)__popcll(m);
                 vmask[fr] = 0;
@@ -368,9 +407,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             const u32 v0 = (u32)__builtin_amdgcn_readlane((int)fr, leader);  // leader is wave-uniform
             const unsigned long long m = __ballot(small && !uniq && !masked && fr == v0);
             if (small && !uniq && !masked && fr == v0) {
-                const u32 pos = cnt[v0] + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                oF[pos] = fr;
-                oS[pos] = (u16)s;
+                place(cnt[v0] + (u32)__popcll(m & ((1ull << lane) - 1ull)), fr, s);
             }
             // one wave: LDS operations execute in program order, so the cursor update below
             // follows the reads above without a barrier (a barrier here would also drain the
@@ -384,10 +421,17 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     const u32 nbig = sh_nbig < nbig_cap ? sh_nbig : nbig_cap;
     for (u32 i = lane; i < nbig; i += 64) {
         const u64 key = big_keys[i];
-        u32 rank = 0;
-        for (u32 j = 0; j < nbig; j++) rank += (big_keys[j] < key) ? 1u : 0u;
-        oF[nsmall + rank] = (u32)(key >> 16);
-        oS[nsmall + rank] = (u16)(key & 0xFFFFu);
+        u32 rank = 0, before = small_mass;
+        for (u32 j = 0; j < nbig; j++) {
+            const bool lt = big_keys[j] < key;
+            rank += lt ? 1u : 0u;
+            before += lt ? (u32)(big_keys[j] >> 16) : 0u;
+        }
+        if (oP) oP[nsmall + rank] = make_uint2(((u32)(key >> 16) & 0xFFFFu) | ((u32)(key & 0xFFFFu) << 16), ntot - before);
+        else {
+            oF[nsmall + rank] = (u32)(key >> 16);
+            oS[nsmall + rank] = (u16)(key & 0xFFFFu);
+        }
     }
     // entropy, util.hpp:271-282
     const double nd = (double)total;
@@ -792,6 +836,8 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
             atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)chosen)
+            atomicMax(&gflags[ANSX_G_MAXT], (u32)chosen);
     }
 }
 

@@ -120,8 +120,8 @@ def cpu_baseline(sample, kind, f, block_ints=16384, budget_s=12.0):
 
 
 def pmc_traffic(kernel, workload):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes, gfx950
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this workload
+    (profiles/*_hbm_traffic_pmc.json, one per profiled configuration: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes, gfx950
     correction calibrated on k_fold_hist).  Counters cannot be read from inside this process, so the
     figure is REPLAYED from that file and only when its workload string is this run's; returns
     (bytes, source) or (None, reason)."""
@@ -129,16 +129,23 @@ def pmc_traffic(kernel, workload):
         paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
         if not paths:
             return None, "no PMC summary under profiles/"
-        with open(paths[-1]) as fh:
-            best = json.load(fh)
-        rel = os.path.relpath(paths[-1], ROOT)
-        if best.get("workload") != workload:
-            return None, "%s profiles a different workload (%s)" % (rel, best.get("workload"))
+        best = rel = None
+        seen = set()
+        for path in reversed(paths):  # newest (by name: r<round>_<tag>) summary of THIS workload
+            with open(path) as fh:
+                doc = json.load(fh)
+            seen.add(doc.get("workload"))
+            if doc.get("workload") == workload:
+                best, rel = doc, os.path.relpath(path, ROOT)
+                break
+        if best is None:
+            return None, "no PMC summary under profiles/ for this workload (profiled: %s)" % "; ".join(sorted(str(x) for x in seen))
         for name, v in best["kernels"].items():
             base = name.split("<")[0]
             # profile labels are the launch sites' ("k_decode", "k_encode_gtab"), the PMC summary has the
             # kernels' own names ("k_decode_rank<...>", "k_encode<2, ...>")
-            if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode"):
+            if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode") \
+                    or (kernel == "k_rfold_remap" and base.startswith("k_rfold_remap")):
                 return v["hbm_bytes"], "replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
         return None, "%s has no entry for %s" % (rel, kernel)
     except Exception as exc:  # noqa: BLE001

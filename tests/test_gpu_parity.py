@@ -28,13 +28,16 @@ def A():
     return A_
 
 
-@pytest.fixture(scope="module", params=["learned", "hinted", "fused"])
+@pytest.fixture(scope="module", params=["learned", "hinted", "hinted5", "hinted-exact", "fused"])
 def ctx(A, oracle_built, request):
     """"learned": a fresh context -- the first call per geometry discovers the alphabet size with a
     mid-call read-back, later ones are launched back to back on the learned hint.  "hinted": the hint
     is forced from the first call on (ANSX_NS_HINT), so every eligible encode of the suite takes the
-    read-back-free path; inputs that outgrow it repeat on the discovery path.  "fused": additionally the
-    single LDS-resident model kernel (k_model_fused, opt-in) replaces the five tailored ones."""
+    read-back-free path with the fast model kernels (k_candidates / k_model_finish, 8 candidate frame sizes per
+    block: ANSX_T_HINT); inputs that outgrow it repeat on the discovery path.  "hinted5": the same with 5
+    candidates per block (12 blocks per wave; blocks that need a sixth repeat).  "hinted-exact": the hinted path
+    with the exact model kernels (ANSX_NO_FAST_MODEL).  "fused": the single LDS-resident model kernel
+    (k_model_fused, opt-in) instead."""
     # Same order as bench.py: torch (which bundles its own HIP runtime) initialises the device
     # first, libansx then shares that runtime.  On a fresh box the first `import torch` can take
     # minutes while the image pages in; doing it here keeps that out of the individual tests.
@@ -48,6 +51,12 @@ def ctx(A, oracle_built, request):
     c = A.Context(0)
     if request.param != "learned":
         c.debug_set("ANSX_NS_HINT", "4096")
+    if request.param == "hinted":
+        c.debug_set("ANSX_T_HINT", "8")
+    if request.param == "hinted5":
+        c.debug_set("ANSX_T_HINT", "5")
+    if request.param == "hinted-exact":
+        c.debug_set("ANSX_NO_FAST_MODEL", "1")
     if request.param == "fused":
         c.debug_set("ANSX_MODEL_FUSED", "1")
     return c
@@ -780,6 +789,11 @@ def test_hinted_paths_run_and_match(A, kind, f, fam, oracle_built):
             assert "k_model_fused" in k2 and "k_fold_hist" not in k2 and "k_scale_attempts" not in k2
         else:
             assert k2.count("k_fold_hist") == 1 and "k_model_fused" not in k2
+            # geometries whose blocks settle within 8 candidate frame sizes take the fast model kernels
+            took_fast = (c.last_encode_stats()["path"] & 4) != 0
+            assert ("k_candidates" in k2) == took_fast and ("k_model_finish" in k2) == took_fast
+            if kind == ol.FOLD and f == 1:
+                assert took_fast and "k_scale_attempts" not in k2 and "k_write_prelude" not in k2
         assert np.array_equal(first, second)
         check_container(A, second, data, kind, f, 16384, 1024)
         # an input with a larger alphabet than the learned hint: miss -> discovery path, hint grows
@@ -791,6 +805,45 @@ def test_hinted_paths_run_and_match(A, kind, f, fam, oracle_built):
         fourth, k4 = _kernels_of(c, lambda: codec.encode(data))
         assert np.array_equal(first, fourth)
         assert "k_fold_hist" in k4 and (("k_model_fused" in k4) == fused)  # tried, missed, repeated
+        c.close()
+
+
+def test_fast_model_path_and_its_repeats(A, oracle_built):
+    """k_candidates / k_model_finish (ansx_fastmodel.h): taken from the second call of a geometry on, byte-identical
+    to the exact kernels; a comparison inside the guard band of the stop rule (forced here by widening the band),
+    too few candidate lanes for some block, or an alphabet above the hint repeat the call on the exact path."""
+    n = 9 * 16384 + 4321
+    for kind, f, fam in ((ol.FOLD, 1, "zipf20s1.2"), (ol.FOLD, 3, "zipf24"), (ol.RFOLD, 3, "zipf24"), (ol.MSB, 0, "zipf20s1.2"),
+                         (ol.FOLD, 1, "uniform256"), (ol.FOLD, 5, "geom0.01")):
+        data = ol.gen_inputs(fam, n, seed=91)
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        c = A.Context(0)
+        codec = codec_for(A, c, kind, f, block_ints=16384, ckpt_interval=1024)
+        first = codec.encode(data)                       # discovery: exact kernels, learns the hints
+        assert c.last_encode_stats()["path"] == 0
+        second, k2 = _kernels_of(c, lambda: codec.encode(data))
+        st = c.last_encode_stats()
+        if f <= 3:                                       # (f = 5: 16384-slot alphabets stay on the exact path)
+            assert st["path"] == 5 and "k_candidates" in k2 and "k_scale_attempts" not in k2, (kind, f, fam, st)
+        assert np.array_equal(first, second)
+        check_container(A, second, data, kind, f, 16384, 1024)
+        if f > 3:
+            c.close()
+            continue
+        c.debug_set("ANSX_FAST_GUARD", "0.5")            # every comparison counts as too close: repeat
+        third, k3 = _kernels_of(c, lambda: codec.encode(data))
+        assert c.last_encode_stats()["path"] & 16 and "k_candidates" in k3 and "k_scale_attempts" in k3
+        assert np.array_equal(first, third)
+        c.debug_set("ANSX_FAST_GUARD", None)
+        c.debug_set("ANSX_T_HINT", "4")                  # four candidate lanes: blocks that need a fifth repeat
+        fourth = codec.encode(data)
+        assert np.array_equal(first, fourth)
+        c.debug_set("ANSX_T_HINT", None)
+        for _ in range(2):                               # hints recover: the fast path again
+            fifth = codec.encode(data)
+        assert c.last_encode_stats()["path"] == 5 and np.array_equal(first, fifth)
+        assert np.array_equal(codec.decode(fifth, n), data)
         c.close()
 
 

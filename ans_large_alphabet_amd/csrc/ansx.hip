@@ -451,18 +451,21 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
     if (fast) {
         const u32 bpw = 64u / NT;
-        const size_t cl = (size_t)bpw * ANSX_CAND_ROW * 16;
-        LAUNCH(c, "k_candidates", k_candidates, (NB + bpw - 1) / bpw, 64, cl, s, g, NSP, NT, (const uint2*)c->pairs.p,
-            (const ansx_blk*)blk, (u16*)c->attS.p, (u32*)c->attMeta.p, (const double*)c->lg2i.p);
+        const size_t cl = (size_t)ANSX_CAND_WAVES * bpw * ANSX_CAND_ROW * 16;
+        const u32 cwaves = (NB + bpw - 1) / bpw;
+        if (cl > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
+        LAUNCH(c, "k_candidates", k_candidates, (cwaves + ANSX_CAND_WAVES - 1) / ANSX_CAND_WAVES, 64 * ANSX_CAND_WAVES, cl, s, g, NSP, NT,
+            (const uint2*)c->pairs.p, (const ansx_blk*)blk, (uint4*)c->attS.p, (u32*)c->attMeta.p, (const double*)c->lg2i.p);
         const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
         const size_t fl = (size_t)fcap * 12 + 64;
         if (NSP <= 1024) {
-            LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const u32*)hist, (const u16*)c->attS.p,
+            LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
                 (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
         } else {
             if (fl > 48 * 1024)
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
-            LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const u32*)hist, (const u16*)c->attS.p,
+            LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
                 (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
         }
         max_logM = 16;

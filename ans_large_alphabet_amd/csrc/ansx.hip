@@ -48,7 +48,7 @@ struct ansx_ctx {
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i;
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i, sizes;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
@@ -338,6 +338,12 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
+    // per-block stream sizes + their sums per 64 blocks, published by the encoder for k_assemble
+    const size_t ngroups = ((size_t)NB + 63) / 64;
+    if ((rc = ensure(c, c->sizes, ngroups * 8 + (size_t)NB * 4))) return rc;
+    unsigned long long* enc_gsums = (unsigned long long*)c->sizes.p;
+    u32* enc_sizes = (u32*)((u8*)c->sizes.p + ngroups * 8);
+    HIPCHK(c, hipMemsetAsync(enc_gsums, 0, ngroups * 8, s));
     u32* gflags = (u32*)c->misc.p;
     u64* result = (u64*)((u8*)c->misc.p + 16);
     u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
@@ -456,17 +462,17 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         if (cl > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
         LAUNCH(c, "k_candidates", k_candidates, (cwaves + ANSX_CAND_WAVES - 1) / ANSX_CAND_WAVES, 64 * ANSX_CAND_WAVES, cl, s, g, NSP, NT,
-            (const uint2*)c->pairs.p, (const ansx_blk*)blk, (uint4*)c->attS.p, (u32*)c->attMeta.p, (const double*)c->lg2i.p);
+            (const uint2*)c->pairs.p, (const ansx_blk*)blk, (uint4*)c->attS.p, (u32*)c->attMeta.p);
         const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
         const size_t fl = (size_t)fcap * 12 + 64;
         if (NSP <= 1024) {
             LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p);
         } else {
             if (fl > 48 * 1024)
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
             LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard);
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p);
         }
         max_logM = 16;
         max_ns = ns_cap;
@@ -541,11 +547,11 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         if (map_is_pow2(g.map))
             LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off);
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
         else
             LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off);
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
     } else if (f64_ok && !c->dbg.encode_gtab16) {
         // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
         const u32 w2 = (NB + 15) / 16;
@@ -556,20 +562,25 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off);
+            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
     } else {
         LAUNCH(c, "k_encode_gtab", (k_encode<0>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off);
+            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
     }
     // K6
     u64* boff = P.plain ? boff_ws : (u64*)(d_out + P.lay.index_off);
-    LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off,
-        (u64)cap, gflags);
-    LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p,
-        (u64)scr_stride, d_out + P.lay.payload_off, gflags);
-    if (!P.plain)
-        LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    if (NB <= 65536u) {
+        LAUNCH(c, "k_assemble", k_assemble, NB, 256, 0, s, g, (const u32*)enc_sizes, (const unsigned long long*)enc_gsums, boff, result,
+            (const u8*)c->scratch.p, (u64)scr_stride, d_out, (u64)P.lay.payload_off, (u64)cap, gflags, P.plain ? 0u : 1u);
+    } else {
+        LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off,
+            (u64)cap, gflags);
+        LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p,
+            (u64)scr_stride, d_out + P.lay.payload_off, gflags);
+        if (!P.plain)
+            LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (optimistic) {
@@ -651,6 +662,11 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
+    const size_t ngroups = ((size_t)NB + 63) / 64;
+    if ((rc = ensure(c, c->sizes, ngroups * 8 + (size_t)NB * 4))) return rc;
+    unsigned long long* enc_gsums = (unsigned long long*)c->sizes.p;
+    u32* enc_sizes = (u32*)((u8*)c->sizes.p + ngroups * 8);
+    HIPCHK(c, hipMemsetAsync(enc_gsums, 0, ngroups * 8, s));
     u32* gflags = (u32*)c->misc.p;
     u64* result = (u64*)((u8*)c->misc.p + 16);
     ansx_blk* blk = (ansx_blk*)c->blk.p;
@@ -699,11 +715,11 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
         if (map_is_pow2(g.map))
             LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off);
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
         else
             LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
                 (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off);
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
     } else {
         const u32 w2 = (NB + 15) / 16;
         u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
@@ -713,13 +729,18 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
             HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
             (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off);
+            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
     }
     u64* boff = (u64*)(d_out + P.lay.index_off);
-    LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off, (u64)cap, gflags);
-    LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p, (u64)scr_stride,
-        d_out + P.lay.payload_off, gflags);
-    LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    if (NB <= 65536u) {
+        LAUNCH(c, "k_assemble", k_assemble, NB, 256, 0, s, g, (const u32*)enc_sizes, (const unsigned long long*)enc_gsums, boff, result,
+            (const u8*)c->scratch.p, (u64)scr_stride, d_out, (u64)P.lay.payload_off, (u64)cap, gflags, 1u);
+    } else {
+        LAUNCH(c, "k_scan_sizes", k_scan_sizes, 1, 1024, 0, s, g, blk, boff, result, P.lay.payload_off, (u64)cap, gflags);
+        LAUNCH(c, "k_compact", k_compact, NB, 256, 0, s, g, blk, boff, (const u8*)c->scratch.p, (u64)scr_stride,
+            d_out + P.lay.payload_off, gflags);
+        LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const u32 fl = c->h_pin[ANSX_G_ERR];
@@ -1145,6 +1166,23 @@ int ansx_last_encode_stats(const ansx_ctx* c, ansx_encode_stats* out)
 {
     if (!c || !out) return ANSX_ERR_ARG;
     *out = c->last;
+#ifdef ANSX_STAMPS
+    {
+        static unsigned long long h[16 * 256];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
+            double acc[16] = {};
+            int nn = 0;
+            for (int w = 0; w < 256; w++) {
+                if (!h[w * 16] || !h[w * 16 + 10]) continue;
+                nn++;
+                for (int i = 1; i <= 10; i++) acc[i] += (double)(h[w * 16 + i] - h[w * 16 + i - 1]);
+            }
+            fprintf(stderr, "[stamps] %d workgroups, 100 MHz ticks per phase:", nn);
+            for (int i = 1; i <= 10; i++) fprintf(stderr, " %d:%.0f", i, nn ? acc[i] / nn : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return ANSX_OK;
 }
 
@@ -1179,7 +1217,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {
@@ -1444,7 +1482,7 @@ size_t ansx_workspace_bytes(const ansx_ctx* c)
     if (!c) return 0;
     const DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info, &c->pairs };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info, &c->pairs, &c->sizes };
     size_t t = 0;
     for (const DevBuf* b : bufs) t += b->cap;
     return t;

@@ -2,10 +2,10 @@
 // geometry the context has seen before.  Same results as k_scale_attempts / k_select_model / k_write_prelude
 // (ansx_kernels.h), which remain the exact path every deviation falls back to:
 //
-//   k_candidates     scale_freqs (ans_util.hpp:77-95) for NT frame sizes per block, one lane each, and the cross
-//                    entropy of every candidate (util.hpp:284-298) accumulated in the same pass
-//   k_model_finish   stop rule (ans_util.hpp:127-153), encoder table (ans_fold.hpp:82-91) and prelude
-//                    (ans_util.hpp:46-63) of the chosen frame in one workgroup per block
+//   k_candidates     scale_freqs (ans_util.hpp:77-95) for NT frame sizes per block, one lane each
+//   k_model_finish   cross entropy of every candidate (util.hpp:284-298), stop rule (ans_util.hpp:127-153), encoder
+//                    table (ans_fold.hpp:82-91) and prelude (ans_util.hpp:46-63) of the chosen frame, one workgroup
+//                    per block
 //
 // What makes it fast, and why the bytes cannot differ:
 //  * The normalised frequencies S are integers produced by exactly the reference's double operations
@@ -14,8 +14,8 @@
 //    not depend on the frame size), and a candidate whose remaining frame goes negative simply runs on (the
 //    remainder only decreases, so "M_rem != 0" at the end is the reference's failure test, ans_util.hpp:90-94).
 //  * The stop rule compares XH = -sum p log2(S/M) with 1.001 H.  The reference sums both left to right in symbol
-//    order; here XH is accumulated in rank order as log2 M - (sum F log2 S) / n from a table of log2 of the
-//    integers, and H is a tree sum (k_fold_hist).  Both agree with the reference-order sums to ~1e-13 relative.
+//    order; here XH is a tree sum in rank order, log2 M - (sum F log2 S) / n with log2 of the integers from a
+//    table, and H is a tree sum too (k_fold_hist).  Both agree with the reference-order sums to ~1e-13 relative.
 //    Every comparison must therefore clear the threshold by ANSX_FAST_GUARD = 1e-9 relative; a block that does
 //    not (none was ever seen: candidates differ by >= 1e-4) raises the violation flag and the whole call is
 //    repeated on the exact path, which is also where the 1e-12 "near threshold" accounting lives.
@@ -23,10 +23,17 @@
 
 #include "ansx_kernels.h"
 
+#ifdef ANSX_STAMPS  // development: per-phase wall-clock stamps of a few workgroups (printed by ansx_last_encode_stats)
+__device__ unsigned long long g_stamps[16 * 256];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x % 64 == 7 && blockIdx.x / 64 < 256) g_stamps[(blockIdx.x / 64) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define ANSX_FAST_GUARD 1e-9
 #define ANSX_CAND_SL 64u         // symbols per LDS stage (NT = 5: 12.5 KB per wave, three 4-wave workgroups per CU)
 #define ANSX_CAND_ROW (ANSX_CAND_SL + 1u)  // entries per block row (odd: rows start in different banks)
 #define ANSX_CAND_MAXBPW 16u     // blocks per wave (NT >= 4 lanes per block)
+#define ANSX_FIN_LUT 512u        // entries of the log2 table k_model_finish keeps in LDS (larger values: the table in HBM)
 
 // log2 of the integers 0 .. 65535 (entry 0 = 0) with the portable log2: one table per context (512 KB)
 __global__ void k_build_log2i_lut(double* __restrict__ lut)
@@ -56,12 +63,12 @@ ANSX_HD u64 srank_chunk(u32 NSP, u32 NT, u32 b, u32 batch, u32 t) { return ((u64
 #define ANSX_CAND_WAVES 4u
 __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g, u32 NSP, u32 NT,
     const uint2* __restrict__ pairs, const ansx_blk* __restrict__ blk, uint4* __restrict__ srank,
-    u32* __restrict__ attMeta, const double* __restrict__ lg2i)
+    u32* __restrict__ attMeta)
 {
-    extern __shared__ uint4 cand_lds_all[];  // per wave: [BPW][ANSX_CAND_ROW] { freq | sym << 16, -, reciprocal of fs_rem }
+    extern __shared__ double2 cand_lds_all[];  // per wave: [BPW][ANSX_CAND_ROW] { freq, reciprocal of fs_rem }
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const u32 BPW = 64u / NT;
-    uint4* const cand_lds = cand_lds_all + wv * BPW * ANSX_CAND_ROW;
+    double2* const cand_lds = cand_lds_all + wv * BPW * ANSX_CAND_ROW;
     const u32 bl = lane / NT, t = lane - bl * NT;
     const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * ANSX_CAND_WAVES + wv) * BPW));
     if (wb0 >= g.nblocks) return;
@@ -84,13 +91,12 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
     double Md = dead ? -1.0 : (double)((u64)1 << (dead ? 0u : sh));  // (a dead candidate fails: M_rem stays negative)
     double fsd = nd;
     double mx = 0.0;   // largest S so far
-    double W = 0.0;    // sum F * log2(S)
     uint4* const sp = srank + srank_chunk(NSP, NT, live ? b : wb0, 0u, t);  // + batch * NT
-    const uint4* const row = cand_lds + (bl < BPW ? bl : BPW - 1u) * ANSX_CAND_ROW;
+    const double2* const row = cand_lds + (bl < BPW ? bl : BPW - 1u) * ANSX_CAND_ROW;
 
     // staging: the wave's 64 lanes fetch SL pairs of each of its blocks (coalesced) one stage ahead of the
     // recurrence and turn fs_rem into its reciprocal on the way into LDS
-    const u32 niter = BPW * (ANSX_CAND_SL / 64u);  // <= 32
+    const u32 niter = BPW * (ANSX_CAND_SL / 64u);
     uint2 nxt[ANSX_CAND_MAXBPW * (ANSX_CAND_SL / 64u)];
     auto fetch = [&](u32 c0) {
 #pragma unroll
@@ -110,32 +116,25 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
             if (k < niter) {
                 const u32 i = k * 64u + lane;
                 const u32 rem = nxt[k].y ? nxt[k].y : 1u;  // (entries past a block's sigma are never consumed)
-                const double y = ansx_rcp_int31((double)rem);
-                const u64 yb = ansx_f64_to_bits(y);
-                cand_lds[(i / ANSX_CAND_SL) * ANSX_CAND_ROW + (i % ANSX_CAND_SL)] = make_uint4(nxt[k].x, 0u, (u32)yb, (u32)(yb >> 32));
+                cand_lds[(i / ANSX_CAND_SL) * ANSX_CAND_ROW + (i % ANSX_CAND_SL)] =
+                    double2{ (double)(nxt[k].x & 0xFFFFu), ansx_rcp_int31((double)rem) };
             }
         }
     };
-    // one step of scale_freqs (ans_util.hpp:80-92) + this symbol's cross-entropy weight
-    double pF[8], pL[8];  // pending: frequency and log2(S) of the previous 8 steps (table loads in flight)
-#pragma unroll
-    for (int u = 0; u < 8; u++) pF[u] = 0.0, pL[u] = 0.0;
-    auto step = [&](const uint4 e, double& Fd_out, u32& sc_out) {
-        const double Fd = (double)(e.x & 0xFFFFu);
-        const double y = ansx_bits_to_f64((u64)e.z | ((u64)e.w << 32));
+    // one step of scale_freqs (ans_util.hpp:80-92)
+    auto step = [&](const double2 e) -> u32 {
         // RN(M_rem / fs_rem): ansx_div_int31 with the prepared reciprocal
-        const double q = Md * y;
+        const double q = Md * e.y;
         const double r = __builtin_fma(-q, fsd, Md);
-        const double a = __builtin_fma(r, y, q);
-        double v = a * Fd;
+        const double a = __builtin_fma(r, e.y, q);
+        double v = a * e.x;
         v = 0.5 + v;
         v = __builtin_fmax(v, 1.0);  // (u32)v == 0 -> 1 (ans_util.hpp:86); also what a failed candidate keeps subtracting
         const double sd = __builtin_trunc(v);
         Md = Md - sd;
-        fsd = fsd - Fd;
+        fsd = fsd - e.x;
         mx = __builtin_fmax(mx, sd);
-        Fd_out = Fd;
-        sc_out = (u32)sd;
+        return (u32)sd;
     };
     fetch(0);
     for (u32 c0 = 0; c0 < wsig; c0 += ANSX_CAND_SL) {
@@ -146,58 +145,38 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
         const u32 lim = sigma > c0 ? (sigma - c0 < ANSX_CAND_SL ? sigma - c0 : ANSX_CAND_SL) : 0u;
         const u32 wlim = wsig - c0 < ANSX_CAND_SL ? wsig - c0 : ANSX_CAND_SL;
         for (u32 j0 = 0; j0 < wlim; j0 += 8) {
-            uint4 e8[8];
+            double2 e8[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) e8[u] = row[j0 + u];  // (rows have SL + 1 entries, SL % 8 == 0: no overrun)
-            double nF[8];
             u32 nS[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) nF[u] = 0.0, nS[u] = 0u;
+            for (int u = 0; u < 8; u++) nS[u] = 0u;
             if (j0 + 8 <= lim) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) step(e8[u], nF[u], nS[u]);
+                for (int u = 0; u < 8; u++) nS[u] = step(e8[u]);
             } else if (j0 < lim) {
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    if (j0 + u < lim) step(e8[u], nF[u], nS[u]);
+                    if (j0 + u < lim) nS[u] = step(e8[u]);
             }
-            // No vector-memory operation is issued inside the steps: the table loads of the previous batch are the
-            // youngest ones outstanding here (vmcnt is one in-order counter for loads and stores -- a wait placed
-            // behind this batch's store would drain it), and they have had the whole batch to arrive.
-#pragma unroll
-            for (int u = 0; u < 8; u++) W = __builtin_fma(pF[u], pL[u], W);
-#ifndef CAND_NO_STORE
             if (j0 < lim)  // (values above 65535 end in the u16 exit and are never read: the low halves are stored)
                 sp[(u64)((c0 + j0) >> 3) * NT] = make_uint4((nS[0] & 0xFFFFu) | (nS[1] << 16), (nS[2] & 0xFFFFu) | (nS[3] << 16),
                     (nS[4] & 0xFFFFu) | (nS[5] << 16), (nS[6] & 0xFFFFu) | (nS[7] << 16));
-#endif
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                pF[u] = nF[u];
-#ifndef CAND_NO_LUT
-                pL[u] = lg2i[nS[u] < 65535u ? nS[u] : 65535u];
-#else
-                pL[u] = (double)nS[u];
-#endif
-            }
         }
     }
-#pragma unroll
-    for (int u = 0; u < 8; u++) W = __builtin_fma(pF[u], pL[u], W);
     if (!live) return;
-    u32* meta = attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4;
-    const u32 ok = (Md == 0.0) ? 1u : 0u;
-    // XH = -sum (F/n) log2(S / 2^sh) = sh - (sum F log2 S) / n   (sum F = n: every counted symbol has S >= 1)
-    const double XH = (double)sh - W / nd;
-    const u64 xb = ansx_f64_to_bits(XH);
-    *(uint4*)meta = make_uint4(ok, mx >= 4294967295.0 ? 0xFFFFFFFFu : (u32)mx, (u32)xb, (u32)(xb >> 32));
+    // {ok, maxS}: the cross entropy of a successful candidate is k_model_finish's
+    *(uint2*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) = make_uint2((Md == 0.0) ? 1u : 0u, mx >= 4294967295.0 ? 0xFFFFFFFFu : (u32)mx);
 }
 
-// Stop rule over the NT candidates of k_candidates (guard band, see the header of this file), then -- one workgroup
-// of 256 threads per block -- the chosen frequencies by symbol, their exclusive scan (encoder table, compact 4-byte
-// form; thread i owns IPT consecutive symbols) and the prelude (prelude_emit of ansx_kernels.h).
-// Everything the kernel needs is requested before anything is decided (the block's fields, all candidates' results,
-// the rank -> symbol pairs and EVERY candidate's chunk of a thread's 8 ranks): one round trip, then registers.
+// Cross entropy of the NT candidates of k_candidates and the stop rule over them (guard band, see the header of this
+// file), then the chosen frequencies by symbol, their exclusive scan (encoder table, compact 4-byte form; thread i
+// owns IPT consecutive symbols) and the prelude (prelude_emit of ansx_kernels.h).  One workgroup of 256 threads per
+// block.  XH_t = log2 M_t - (sum_j F_j log2 S_t,j) / n: wave w takes the candidates t = w, w + 4, its lane l the
+// 8-rank chunks l, l + 64, ...; a shuffle reduction per candidate.  The first chunk of every lane, the candidates'
+// {ok, maxS} words and a lane's share of the log2 table's first ANSX_FIN_LUT entries (for LDS) are requested together
+// with the block's fields, before anything is known about the block: one round trip for alphabets up to 512 symbols.
+// The wave that holds the chosen candidate then scatters its chunks -- rank order -> symbol order -- into LDS.
 // Anything this path does not cover raises the violation flag and leaves the block without a stream; the host
 // repeats the call on the exact path: undecided after NT candidates, the u16 exit with no earlier success, a
 // frame above 2^16, a comparison inside the guard band (`guard`: ANSX_FAST_GUARD; tests widen it to force the repeat).
@@ -205,43 +184,99 @@ template <int IPT>
 __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 NT, const uint2* __restrict__ pairs,
     const uint4* __restrict__ srank, const u32* __restrict__ attMeta, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard)
+    u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard, const double* __restrict__ lg2i)
 {
     static_assert(IPT % 4 == 0, "table rows are written 16 bytes at a time");
-    constexpr int RPT = (IPT + 7) / 8;  // 8-rank chunks per thread: 256 * 8 * RPT ranks >= 256 * IPT symbols
+    static_assert(ANSX_FIN_LUT == 512, "two table entries per thread");
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
-    const u32 tid = threadIdx.x;
+    __shared__ double lut[ANSX_FIN_LUT];
+    __shared__ double wsum[ANSX_ATTEMPTS];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
     u32* off = lds32;             // [cap]
     u32* bits = lds32 + cap;      // bit buffer; until the prelude is written: the chosen frequencies by symbol
     u32* inc = lds32 + 2 * cap;   // [cap]
     u32* frq = bits;
+    STAMP(0);
     // ---- requests
     const u32 ns = B->max_sym + 1;
     const u32 sigma = B->sigma;
     const double thr = B->thr;
     const u32 m0 = B->m0_log2;
-    uint4 mt[ANSX_ATTEMPTS];
+    const double nd = (double)B->n;
+    uint2 mt[ANSX_ATTEMPTS];
 #pragma unroll
-    for (u32 t = 0; t < ANSX_ATTEMPTS; t++) mt[t] = t < NT ? *(const uint4*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) : make_uint4(0u, 0u, 0u, 0u);
-    uint4 py[RPT][2];            // (freq | sym << 16) of this thread's ranks
-    uint4 ch[RPT][ANSX_ATTEMPTS];  // every candidate's chunk of them
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-        const u32 batch = tid + 256u * r;  // ranks 8 * batch .. + 7
-        const bool in = batch * 8u < NSP;
-        const uint2* pp = pairs + (u64)b * NSP + (in ? batch * 8u : 0u);
+    for (u32 t = 0; t < ANSX_ATTEMPTS; t++) mt[t] = t < NT ? *(const uint2*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) : make_uint2(0u, 0u);
+    const double2 l2 = *(const double2*)(lg2i + 2 * tid);
+    struct chunk {
+        uint4 fa, fb;  // (freq | sym << 16) of the chunk's 8 ranks
+        uint4 s;       // one candidate's 8 frequencies
+    };
+    const uint2* prow = pairs + (u64)b * NSP;
+    auto load_chunk = [&](u32 c, u32 t) -> chunk {
+        const uint2* pp = prow + (u64)c * 8u;
         const uint4 a0 = *(const uint4*)pp, a1 = *(const uint4*)(pp + 2), a2 = *(const uint4*)(pp + 4), a3 = *(const uint4*)(pp + 6);
-        py[r][0] = make_uint4(a0.x, a0.z, a1.x, a1.z);
-        py[r][1] = make_uint4(a2.x, a2.z, a3.x, a3.z);
-#pragma unroll
-        for (u32 t = 0; t < ANSX_ATTEMPTS; t++)
-            ch[r][t] = (t < NT && in) ? srank[srank_chunk(NSP, NT, b, batch, t)] : make_uint4(0u, 0u, 0u, 0u);
-    }
+        chunk k;
+        k.fa = make_uint4(a0.x, a0.z, a1.x, a1.z);
+        k.fb = make_uint4(a2.x, a2.z, a3.x, a3.z);
+        k.s = srank[srank_chunk(NSP, NT, b, c, t)];
+        return k;
+    };
+    // first chunk of this lane for the wave's one or two candidates (chunk index lane < NSP / 8 always: NSP >= 512)
+    const u32 t0 = wv, t1 = wv + 4u;
+    const chunk k0 = load_chunk(lane, t0 < NT ? t0 : 0u);
+    const chunk k1 = load_chunk(lane, t1 < NT ? t1 : 0u);
     for (u32 s = tid; s < cap; s += 256) frq[s] = 0;  // absent symbols have frequency 0
-    // ---- the (wave-uniform) rule, on the same NT results in every thread
+    *(double2*)(lut + 2 * tid) = l2;
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+    // ---- cross entropy of the wave's candidates
+    const u32 nchunks = (sigma + 7u) >> 3;
+    auto xh_chunk = [&](const chunk& k, u32 c) -> double {
+        const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
+        const u32 sv8[8] = { k.s.x & 0xFFFFu, k.s.x >> 16, k.s.y & 0xFFFFu, k.s.y >> 16, k.s.z & 0xFFFFu, k.s.z >> 16, k.s.w & 0xFFFFu, k.s.w >> 16 };
+        // (a value that was above 65535 is seen truncated: such a candidate ends in the u16 exit before its XH is looked at)
+        u32 big = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) big |= sv8[i];
+        // (ranks past sigma in a block's last chunk were stored as S = 0, whose table entry is 0: no masking needed)
+        double w = 0.0;
+        if (big < ANSX_FIN_LUT) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs8[i] & 0xFFFFu), lut[sv8[i]], w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs8[i] & 0xFFFFu), lg2i[sv8[i]], w);
+        }
+        return w;
+    };
+    auto scatter = [&](const chunk& k, u32 c) {
+        const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
+        const u32 sv8[8] = { k.s.x & 0xFFFFu, k.s.x >> 16, k.s.y & 0xFFFFu, k.s.y >> 16, k.s.z & 0xFFFFu, k.s.z >> 16, k.s.w & 0xFFFFu, k.s.w >> 16 };
+        // (symbols of a block are below ns <= cap; ranks past sigma go to a scratch word behind the three arrays)
+#pragma unroll
+        for (int i = 0; i < 8; i++) frq[c * 8u + i < sigma ? fs8[i] >> 16 : 2u * cap + 8u] = sv8[i];
+    };
+    double w0 = 0.0, w1 = 0.0;
+    if (t0 < NT) {
+        if (lane < nchunks) w0 = xh_chunk(k0, lane);
+        for (u32 c = lane + 64u; c < nchunks; c += 64u) w0 = w0 + xh_chunk(load_chunk(c, t0), c);
+        for (int o = 32; o > 0; o >>= 1) w0 = w0 + __shfl_xor(w0, o);
+        if (lane == 0) wsum[t0] = w0;
+    }
+    if (t1 < NT) {
+        if (lane < nchunks) w1 = xh_chunk(k1, lane);
+        for (u32 c = lane + 64u; c < nchunks; c += 64u) w1 = w1 + xh_chunk(load_chunk(c, t1), c);
+        for (int o = 32; o > 0; o >>= 1) w1 = w1 + __shfl_xor(w1, o);
+        if (lane == 0) wsum[t1] = w1;
+    }
+    STAMP(3);
+    __syncthreads();
+    STAMP(4);
+    // ---- the (workgroup-uniform) rule, on the same NT results in every thread
     int chosen = -2, prev = -1;
     bool unsure = false;
 #pragma unroll
@@ -250,10 +285,9 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         if (!mt[t].x) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
         if (mt[t].y >= ANSX_U16_LIMIT) {  // ans_util.hpp:141-145
             chosen = prev;
-            if (chosen == -2) chosen = -1;
             continue;
         }
-        const double XH = ansx_bits_to_f64((u64)mt[t].z | ((u64)mt[t].w << 32));
+        const double XH = (double)(m0 + t) - wsum[t] / nd;
         const double d = XH - thr;
         if ((d < 0 ? -d : d) <= guard * thr || !(thr > 0.0)) unsure = true;  // (H == 0: one-symbol block, exact path)
         else if (XH < thr) chosen = (int)t;  // ans_util.hpp:149
@@ -267,22 +301,14 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         }
         return;
     }
-    __syncthreads();
-    // ---- chosen frequencies: rank order -> symbol order through LDS
-#pragma unroll
-    for (int r = 0; r < RPT; r++) {
-        uint4 c = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (u32 t = 0; t < ANSX_ATTEMPTS; t++)
-            if ((int)t == chosen) c = ch[r][t];
-        const u32 j0 = (tid + 256u * r) * 8u;
-        const u32 fs8[8] = { py[r][0].x, py[r][0].y, py[r][0].z, py[r][0].w, py[r][1].x, py[r][1].y, py[r][1].z, py[r][1].w };
-        const u32 sv8[8] = { c.x & 0xFFFFu, c.x >> 16, c.y & 0xFFFFu, c.y >> 16, c.z & 0xFFFFu, c.z >> 16, c.w & 0xFFFFu, c.w >> 16 };
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (j0 + k < sigma) frq[fs8[k] >> 16] = sv8[k];  // (symbols of a block are below ns <= cap)
+    // ---- chosen frequencies: rank order -> symbol order through LDS, by the wave that holds them
+    if ((u32)chosen == t0 || (u32)chosen == t1) {
+        if (lane < nchunks) scatter((u32)chosen == t0 ? k0 : k1, lane);
+        for (u32 c = lane + 64u; c < nchunks; c += 64u) scatter(load_chunk(c, (u32)chosen), c);
     }
+    STAMP(5);
     __syncthreads();
+    STAMP(6);
     const u32 s0 = tid * IPT;
     u32 fr[IPT];
     u32 sum = 0;
@@ -295,6 +321,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     }
     u32 total;
     u32 base = block_excl_scan<u32>(sum, sh_part, tid, 256, &total);
+    STAMP(7);
     if (s0 < ns) {
         u32* t32 = tab32 + (u64)b * NSP + s0;
 #pragma unroll
@@ -322,6 +349,11 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         if (__hip_atomic_load(&gflags[ANSX_G_MAXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)chosen)
             atomicMax(&gflags[ANSX_G_MAXT], (u32)chosen);
     }
+    STAMP(8);
     __syncthreads();  // frq (= bits) has been read by everyone; inc[] is complete
+    STAMP(9);
+#ifndef FIN_NO_PRELUDE
     prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints);
+#endif
+    STAMP(10);
 }

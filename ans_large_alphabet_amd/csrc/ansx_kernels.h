@@ -1492,9 +1492,17 @@ template <int MODE, bool POW2 = false>
 __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
-    u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off)
+    u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off, u32* __restrict__ sizes,
+    unsigned long long* __restrict__ gsums)
 {
     extern __shared__ u32 lds_tab[];
+    // sizes[b] = bytes of block b's stream, gsums[b / 64] += them: what k_assemble needs to place a block without
+    // a scan kernel in between
+    auto publish_size = [&](ansx_blk* B_, u32 b_, u32 sz) {
+        B_->stream_bytes = sz;
+        sizes[b_] = sz;
+        if (sz) atomicAdd(&gsums[b_ >> 6], (unsigned long long)sz);
+    };
     // A workgroup is 1 to 4 waves, each with its own 16 blocks and tables.  With 1024 single-wave workgroups the
     // dispatcher does not put a CU's four on four different SIMDs, and waves that run the same long loop out of
     // phase compete for the CU's instruction fetch: four waves per workgroup land one per SIMD (0.94 -> 0.79 ms on
@@ -1545,7 +1553,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     if (b >= g.nblocks) return;
     ansx_blk* B = &blk[b];
     if (B->status || !B->resolved || B->pa_sigma == 1) {
-        if (ql == 0) B->stream_bytes = B->pa_sigma == 1 && !B->status ? B->pre_bytes : 0;
+        if (ql == 0) publish_size(B, b, B->pa_sigma == 1 && !B->status ? B->pre_bytes : 0u);
         return;
     }
     const u32 nb = geo_block_n(g, b);
@@ -1925,7 +1933,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     }
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
     st_u64_unaligned(out + L.p + 8 * ql, tab.state(L) - Lb);
-    if (ql == 0) B->stream_bytes = L.p + 32;
+    if (ql == 0) publish_size(B, b, L.p + 32);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2029,6 +2037,85 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
     w[5] = g.nckf;
     *(u64*)(out + 48) = result[0];
     *(u64*)(out + 56) = payload_off;
+}
+
+// K6, fused form (up to 65536 blocks): one workgroup per block places and copies its stream without a scan kernel
+// in front -- the bytes before block b are the sums of the 64-block groups before it (gsums, accumulated by the
+// encoder) plus the sizes of the blocks of its own group below it: at most 1024 + 63 words, one or two loads per
+// thread.  The workgroup of the last block also writes the index's final entry, the payload size and the header.
+__global__ __launch_bounds__(256) void k_assemble(ansx_geo g, const u32* __restrict__ sizes,
+    const unsigned long long* __restrict__ gsums, u64* __restrict__ block_off, u64* __restrict__ result,
+    const u8* __restrict__ scratch, u64 scr_stride, u8* __restrict__ out, u64 payload_off, u64 capacity,
+    u32* __restrict__ gflags, u32 with_header)
+{
+    __shared__ u64 part[8];
+    const u32 b = blockIdx.x;
+    const u32 tid = threadIdx.x;
+    const u32 size = sizes[b];
+    u64 acc = 0;
+    for (u32 i = tid; i < (b >> 6); i += 256) acc += gsums[i];
+    {
+        const u32 i = (b & ~63u) + tid;
+        if (tid < 64 && i < b) acc += sizes[i];
+    }
+    u64 tot;
+    (void)block_excl_scan<u64>(acc, part, tid, 256, &tot);
+    const u64 off = tot;
+    const bool fits = payload_off + off + size <= capacity;
+    if (tid == 0) {
+        block_off[b] = off;
+        if (!fits) atomicOr(&gflags[ANSX_G_ERR], 1u << 2 /* CAPACITY */);
+        if (b == g.nblocks - 1) {
+            const u64 total = off + size;
+            block_off[g.nblocks] = total;
+            result[0] = total;  // payload bytes
+            if (with_header) {
+                // ansx_container_header, little endian (include/ansx.h)
+                const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
+                for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
+                u32* w = (u32*)(out + 8);
+                w[0] = g.kind | (g.pa ? 0x100u : 0u);  // bit 8: per-block alphabet compaction
+                w[1] = g.f;
+                *(u64*)(out + 16) = g.n;
+                w = (u32*)(out + 24);
+                w[0] = g.block_ints;
+                w[1] = g.ckpt;
+                w[2] = g.nblocks;
+                w[3] = __hip_atomic_load(&gflags[ANSX_G_MAXLOGM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w[4] = __hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w[5] = g.nckf;
+                *(u64*)(out + 48) = total;
+                *(u64*)(out + 56) = payload_off;
+            }
+        }
+    }
+    // (a capacity / domain / model error makes the output invalid anyway: blocks that still fit are copied, the
+    // call reports the error)
+    if (!fits || size == 0) return;
+    const u8* src = scratch + (u64)b * scr_stride;
+    u8* dst = out + payload_off + off;
+    // head: bytes until dst is 16-byte aligned; then 16-byte pieces, four of them requested before the first is stored
+    u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (head > size) head = size;
+    if (tid < head) dst[tid] = src[tid];
+    const u32 nq = (size - head) >> 4;
+    uint4* d16 = (uint4*)(dst + head);
+    const u8* s1 = src + head;
+    auto ld16 = [&](u32 j) {
+        const u8* p = s1 + 16 * (u64)j;
+        return make_uint4(ld_u32_unaligned(p), ld_u32_unaligned(p + 4), ld_u32_unaligned(p + 8), ld_u32_unaligned(p + 12));
+    };
+    u32 j = tid;
+    for (; j + 3 * 256 < nq; j += 4 * 256) {
+        const uint4 v0 = ld16(j), v1 = ld16(j + 256), v2 = ld16(j + 512), v3 = ld16(j + 768);
+        d16[j] = v0;
+        d16[j + 256] = v1;
+        d16[j + 512] = v2;
+        d16[j + 768] = v3;
+    }
+    for (; j < nq; j += 256) d16[j] = ld16(j);
+    const u32 done = head + 16 * nq;
+    if (done + tid < size) dst[done + tid] = src[done + tid];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -181,7 +181,7 @@ def kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_byt
     # reads c and writes 4; other kernels are priced by what they must touch
     enc, dec = (4 + c_bytes) * n, (c_bytes + 4) * n
     alg = {"k_encode": enc, "k_encode_gtab": enc, "k_decode": dec, "k_decode_gtab": dec, "k_decode_table": dec,
-           "k_fold_hist": 4.0 * n, "k_model_fused": 4.0 * n, "k_compact": 2 * c_bytes * n,
+           "k_fold_hist": 4.0 * n, "k_model_fused": 4.0 * n, "k_compact": 2 * c_bytes * n, "k_assemble": 2 * c_bytes * n,
            "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
     achieved = alg / (avg_ms * 1e-3) / 1e9
     traffic, source = pmc_traffic(dom, workload)

@@ -78,6 +78,7 @@ struct ansx_ctx {
         u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
         u32 t_hint = 0;               // ANSX_T_HINT: candidates per block for every call (0 = learn per geometry)
         bool no_fast_model = false;   // ANSX_NO_FAST_MODEL: optimistic calls keep the exact model kernels
+        u32 cand_chains = 0;          // ANSX_CAND_CHAINS: 1 | 2 recurrences per lane in k_candidates (0 = by the call's size)
         double fast_guard = ANSX_FAST_GUARD;  // ANSX_FAST_GUARD: relative guard band of the fast model path's stop rule (tests widen it)
     } dbg;
 };
@@ -457,12 +458,31 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
     if (fast) {
         const u32 bpw = 64u / NT;
-        const size_t cl = (size_t)ANSX_CAND_WAVES * bpw * ANSX_CAND_ROW * 16;
-        const u32 cwaves = (NB + bpw - 1) / bpw;
-        if (cl > 48 * 1024)
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
-        LAUNCH(c, "k_candidates", k_candidates, (cwaves + ANSX_CAND_WAVES - 1) / ANSX_CAND_WAVES, 64 * ANSX_CAND_WAVES, cl, s, g, NSP, NT,
-            (const uint2*)c->pairs.p, (const ansx_blk*)blk, (uint4*)c->attS.p, (u32*)c->attMeta.p);
+        // chains per lane: one while that leaves at most one wave per SIMD, else two (see k_candidates)
+        const u32 nch = c->dbg.cand_chains ? c->dbg.cand_chains : (((NB + bpw - 1) / bpw <= 4u * c->num_cus) ? 1u : 2u);
+        const size_t cl = (size_t)ANSX_CAND_WAVES * nch * bpw * ANSX_CAND_ROW * 16;
+        const u32 cwaves = (NB + nch * bpw - 1) / (nch * bpw);
+#define ANSX_LAUNCH_CAND2(NT_, NCH_)                                                                                    \
+    do {                                                                                                            \
+        if (cl > 48 * 1024)                                                                                         \
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_candidates<NT_, NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl)); \
+        LAUNCH(c, "k_candidates", (k_candidates<NT_, NCH_>), (cwaves + ANSX_CAND_WAVES - 1) / ANSX_CAND_WAVES, 64 * ANSX_CAND_WAVES, cl, s, g, NSP, \
+            (const uint2*)c->pairs.p, (const ansx_blk*)blk, (uint4*)c->attS.p, (u32*)c->attMeta.p);               \
+    } while (0)
+#define ANSX_LAUNCH_CAND(NT_)                                                                                           \
+    do {                                                                                                            \
+        if (nch == 1) ANSX_LAUNCH_CAND2(NT_, 1);                                                                    \
+        else ANSX_LAUNCH_CAND2(NT_, 2);                                                                             \
+    } while (0)
+        switch (NT) {
+        case 4: ANSX_LAUNCH_CAND(4); break;
+        case 5: ANSX_LAUNCH_CAND(5); break;
+        case 6: ANSX_LAUNCH_CAND(6); break;
+        case 7: ANSX_LAUNCH_CAND(7); break;
+        default: ANSX_LAUNCH_CAND(8); break;
+        }
+#undef ANSX_LAUNCH_CAND
+#undef ANSX_LAUNCH_CAND2
         const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
         const size_t fl = (size_t)fcap * 12 + 64;
         if (NSP <= 1024) {
@@ -1155,7 +1175,7 @@ int ansx_init(int device, ansx_ctx** out)
         return ANSX_ERR_HIP;
     }
     static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN", "ANSX_PARSE_FAST",
-        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD" };
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD", "ANSX_CAND_CHAINS" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
@@ -1180,6 +1200,11 @@ int ansx_last_encode_stats(const ansx_ctx* c, ansx_encode_stats* out)
             fprintf(stderr, "[stamps] %d workgroups, 100 MHz ticks per phase:", nn);
             for (int i = 1; i <= 10; i++) fprintf(stderr, " %d:%.0f", i, nn ? acc[i] / nn : 0.0);
             fprintf(stderr, "\n");
+            double cc = 0, cl = 0, ct = 0;
+            int n2 = 0;
+            for (int w = 0; w < 256; w++)
+                if (h[w * 16 + 14]) cc += (double)h[w * 16 + 12], cl += (double)h[w * 16 + 13], ct += (double)h[w * 16 + 14], n2++;
+            if (n2) fprintf(stderr, "[stamps] k_candidates (%d waves): commit %.0f loop %.0f total %.0f ticks\n", n2, cc / n2, cl / n2, ct / n2);
         }
     }
 #endif
@@ -1205,7 +1230,11 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NS_HINT")) c->dbg.ns_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
-    else if (!strcmp(name, "ANSX_FAST_GUARD")) c->dbg.fast_guard = (value && value[0]) ? strtod(value, nullptr) : ANSX_FAST_GUARD;
+    else if (!strcmp(name, "ANSX_CAND_CHAINS")) {
+        const u32 v = value ? (u32)strtoul(value, nullptr, 10) : 0u;
+        if (v > 2) return ANSX_ERR_ARG;
+        c->dbg.cand_chains = v;
+    } else if (!strcmp(name, "ANSX_FAST_GUARD")) c->dbg.fast_guard = (value && value[0]) ? strtod(value, nullptr) : ANSX_FAST_GUARD;
     else return ANSX_ERR_ARG;
     return ANSX_OK;
 }

@@ -56,117 +56,205 @@ __device__ __forceinline__ double ansx_rcp_int31(double b)
 // block and STEP: 0.066 of this kernel's 0.18 ms on the headline workload.)
 ANSX_HD u64 srank_chunk(u32 NSP, u32 NT, u32 b, u32 batch, u32 t) { return ((u64)b * (NSP / 8u) + batch) * NT + t; }
 
-// NT lanes per block (candidate frame sizes M0 * 2^t, t < NT), 64 / NT blocks per wave; ANSX_CAND_WAVES independent
-// waves per workgroup, each with its own blocks and LDS slice and never synchronised (single-wave workgroups pile up
-// unevenly on a CU's SIMDs; waves of one workgroup land one per SIMD).
-// pairs: k_sort_entropy's packed output.  attMeta: {ok, maxS, XH bits} per (block, t) as k_scale_attempts writes it.
+// NT lanes per block group (candidate frame sizes M0 * 2^t, t < NT).  A lane carries NCH independent recurrences --
+// the same t of NCH blocks.  NCH = 1 while one chain per lane gives at most one wave per SIMD; beyond that NCH = 2,
+// interleaved step by step: the step is a chain of 8 dependent f64 operations, and the 16384 x 5 chains of the
+// headline workload are 1366 waves, more than the chip's 1024 SIMDs but not enough for two on each; two chains per
+// lane halve the waves and fill each other's latency.  A wave covers NCH * (64 / NT) consecutive blocks; ANSX_CAND_WAVES independent waves per
+// workgroup, each with its own LDS slice and never synchronised (single-wave workgroups pile up unevenly on a CU's
+// SIMDs; waves of one workgroup land one per SIMD).
+// pairs: k_sort_entropy's packed output.  attMeta: {ok, maxS} per (block, t).
 #define ANSX_CAND_WAVES 4u
-__global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g, u32 NSP, u32 NT,
+template <u32 NT, u32 NCH>  // compile-time: every staging load of a stage must be in flight at once (with a run-time trip count
+                   // hipcc gives each load its own basic block and a full wait: 7 us per stage instead of one round trip)
+__global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g, u32 NSP,
     const uint2* __restrict__ pairs, const ansx_blk* __restrict__ blk, uint4* __restrict__ srank,
     u32* __restrict__ attMeta)
 {
-    extern __shared__ double2 cand_lds_all[];  // per wave: [BPW][ANSX_CAND_ROW] { freq, reciprocal of fs_rem }
+    extern __shared__ double2 cand_lds_all[];  // per wave: [2 BPW][ANSX_CAND_ROW] { freq, reciprocal of fs_rem }
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32 BPW = 64u / NT;
-    double2* const cand_lds = cand_lds_all + wv * BPW * ANSX_CAND_ROW;
+    constexpr u32 BPW = 64u / NT;
+    constexpr u32 rows = NCH * BPW;
+    double2* const cand_lds = cand_lds_all + wv * rows * ANSX_CAND_ROW;
     const u32 bl = lane / NT, t = lane - bl * NT;
-    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * ANSX_CAND_WAVES + wv) * BPW));
+    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * ANSX_CAND_WAVES + wv) * rows));
     if (wb0 >= g.nblocks) return;
-    const u32 b = wb0 + bl;
-    const bool live = bl < BPW && b < g.nblocks;
-    u32 sigma = 0, sh = 0;
-    double nd = 1.0;
-    if (live) {
-        const ansx_blk* B = &blk[b];
-        sigma = B->sigma;
-        sh = B->m0_log2 + t;
-        nd = (double)B->n;
+    u32 bb[NCH], sigma[NCH], sh[NCH];
+    bool live[NCH];
+    double Md[NCH], fsd[NCH], mx[NCH];
+    uint4* sp[NCH];
+    const double2* row[NCH];
+    u32 wsig = 0;
+#pragma unroll
+    for (u32 c = 0; c < NCH; c++) {
+        bb[c] = wb0 + c * BPW + bl;
+        live[c] = bl < BPW && bb[c] < g.nblocks;
+        sigma[c] = 0, sh[c] = 0;
+        double nd = 1.0;
+        if (live[c]) {
+            const ansx_blk* B = &blk[bb[c]];
+            sigma[c] = B->sigma;
+            sh[c] = B->m0_log2 + t;
+            nd = (double)B->n;
+        }
+        wsig = sigma[c] > wsig ? sigma[c] : wsig;
+        const bool dead = sh[c] > 31;  // frame sizes beyond 2^31 are unreachable for valid inputs
+        Md[c] = dead ? -1.0 : (double)((u64)1 << (dead ? 0u : sh[c]));  // (a dead candidate fails: M_rem stays negative)
+        fsd[c] = nd;
+        mx[c] = 0.0;  // largest S so far
+        sp[c] = srank + srank_chunk(NSP, NT, live[c] ? bb[c] : wb0, 0u, t);  // + batch * NT
+        row[c] = cand_lds + (c * BPW + (bl < BPW ? bl : BPW - 1u)) * ANSX_CAND_ROW;
     }
-    u32 wsig = sigma;  // the wave runs as long as its longest block
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 32; o > 0; o >>= 1) {  // the wave runs as long as its longest block
         const u32 x = (u32)__shfl_xor((int)wsig, o);
         wsig = x > wsig ? x : wsig;
     }
-    const bool dead = sh > 31;  // frame sizes beyond 2^31 are unreachable for valid inputs
-    double Md = dead ? -1.0 : (double)((u64)1 << (dead ? 0u : sh));  // (a dead candidate fails: M_rem stays negative)
-    double fsd = nd;
-    double mx = 0.0;   // largest S so far
-    uint4* const sp = srank + srank_chunk(NSP, NT, live ? b : wb0, 0u, t);  // + batch * NT
-    const double2* const row = cand_lds + (bl < BPW ? bl : BPW - 1u) * ANSX_CAND_ROW;
-
     // staging: the wave's 64 lanes fetch SL pairs of each of its blocks (coalesced) one stage ahead of the
     // recurrence and turn fs_rem into its reciprocal on the way into LDS
-    const u32 niter = BPW * (ANSX_CAND_SL / 64u);
-    uint2 nxt[ANSX_CAND_MAXBPW * (ANSX_CAND_SL / 64u)];
+    constexpr u32 NITER = rows * (ANSX_CAND_SL / 64u);
+    uint2 nxt[NITER];
+    const u32 last_b = g.nblocks - 1u;
     auto fetch = [&](u32 c0) {
 #pragma unroll
-        for (u32 k = 0; k < ANSX_CAND_MAXBPW * (ANSX_CAND_SL / 64u); k++) {
-            if (k < niter) {
-                const u32 i = k * 64u + lane;
-                const u32 bb = wb0 + i / ANSX_CAND_SL;
-                u32 j = c0 + (i % ANSX_CAND_SL);
-                j = j < NSP ? j : NSP - 1u;  // rows are NSP entries long
-                nxt[k] = bb < g.nblocks ? pairs[(u64)bb * NSP + j] : make_uint2(0u, 1u);
-            }
+        for (u32 k = 0; k < NITER; k++) {
+            const u32 i = k * 64u + lane;
+            u32 b2 = wb0 + i / ANSX_CAND_SL;
+            b2 = b2 < last_b ? b2 : last_b;  // (rows past the last block: any valid address, never consumed)
+            u32 j = c0 + (i % ANSX_CAND_SL);
+            j = j < NSP ? j : NSP - 1u;  // rows are NSP entries long
+            nxt[k] = pairs[(u64)b2 * NSP + j];
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (u32 k = 0; k < ANSX_CAND_MAXBPW * (ANSX_CAND_SL / 64u); k++) {
-            if (k < niter) {
-                const u32 i = k * 64u + lane;
-                const u32 rem = nxt[k].y ? nxt[k].y : 1u;  // (entries past a block's sigma are never consumed)
-                cand_lds[(i / ANSX_CAND_SL) * ANSX_CAND_ROW + (i % ANSX_CAND_SL)] =
-                    double2{ (double)(nxt[k].x & 0xFFFFu), ansx_rcp_int31((double)rem) };
-            }
+        for (u32 k = 0; k < NITER; k++) {
+            const u32 i = k * 64u + lane;
+            const u32 rem = nxt[k].y ? nxt[k].y : 1u;  // (entries past a block's sigma are never consumed)
+            cand_lds[(i / ANSX_CAND_SL) * ANSX_CAND_ROW + (i % ANSX_CAND_SL)] =
+                double2{ (double)(nxt[k].x & 0xFFFFu), ansx_rcp_int31((double)rem) };
         }
     };
-    // one step of scale_freqs (ans_util.hpp:80-92)
-    auto step = [&](const double2 e) -> u32 {
+    // one step of scale_freqs (ans_util.hpp:80-92) of chain c
+    auto step = [&](u32 c, const double2 e) -> u32 {
         // RN(M_rem / fs_rem): ansx_div_int31 with the prepared reciprocal
-        const double q = Md * e.y;
-        const double r = __builtin_fma(-q, fsd, Md);
+        const double q = Md[c] * e.y;
+        const double r = __builtin_fma(-q, fsd[c], Md[c]);
         const double a = __builtin_fma(r, e.y, q);
         double v = a * e.x;
         v = 0.5 + v;
         v = __builtin_fmax(v, 1.0);  // (u32)v == 0 -> 1 (ans_util.hpp:86); also what a failed candidate keeps subtracting
         const double sd = __builtin_trunc(v);
-        Md = Md - sd;
-        fsd = fsd - e.x;
-        mx = __builtin_fmax(mx, sd);
+        Md[c] = Md[c] - sd;
+        fsd[c] = fsd[c] - e.x;
+        mx[c] = __builtin_fmax(mx[c], sd);
         return (u32)sd;
     };
+#ifdef ANSX_STAMPS
+    unsigned long long tc0 = wall_clock64(), t_commit = 0, t_loop = 0, t_a = 0;
+#endif
     fetch(0);
     for (u32 c0 = 0; c0 < wsig; c0 += ANSX_CAND_SL) {
+#ifdef ANSX_STAMPS
+        t_a = wall_clock64();
+#endif
         wave_lds_sync();  // the previous stage has been consumed (one wave: LDS operations are in order)
         commit();
         if (c0 + ANSX_CAND_SL < wsig) fetch(c0 + ANSX_CAND_SL);
         wave_lds_sync();
-        const u32 lim = sigma > c0 ? (sigma - c0 < ANSX_CAND_SL ? sigma - c0 : ANSX_CAND_SL) : 0u;
+        u32 lim[NCH];
+#pragma unroll
+        for (u32 c = 0; c < NCH; c++) lim[c] = sigma[c] > c0 ? (sigma[c] - c0 < ANSX_CAND_SL ? sigma[c] - c0 : ANSX_CAND_SL) : 0u;
         const u32 wlim = wsig - c0 < ANSX_CAND_SL ? wsig - c0 : ANSX_CAND_SL;
+#ifdef ANSX_STAMPS
+        { const unsigned long long tb = wall_clock64(); t_commit += tb - t_a; t_a = tb; }
+#endif
         for (u32 j0 = 0; j0 < wlim; j0 += 8) {
-            double2 e8[8];
+            double2 e8[NCH][8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) e8[u] = row[j0 + u];  // (rows have SL + 1 entries, SL % 8 == 0: no overrun)
-            u32 nS[8];
+            for (u32 c = 0; c < NCH; c++)
 #pragma unroll
-            for (int u = 0; u < 8; u++) nS[u] = 0u;
-            if (j0 + 8 <= lim) {
+                for (int u = 0; u < 8; u++) e8[c][u] = row[c][j0 + u];  // (rows have SL + 1 entries, SL % 8 == 0: no overrun)
+            u32 nS[NCH][8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) nS[u] = step(e8[u]);
-            } else if (j0 < lim) {
+            for (u32 c = 0; c < NCH; c++)
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (j0 + u < lim) nS[u] = step(e8[u]);
+                for (int u = 0; u < 8; u++) nS[c][u] = 0u;
+            bool all_full = true;
+#pragma unroll
+            for (u32 c = 0; c < NCH; c++) all_full = all_full && (j0 + 8 <= lim[c]);
+            if (all_full) {
+                // The two chains operation by operation, in the written order (a scheduling barrier after every
+                // line): hipcc's own schedule runs six dependent operations of one chain back to back, and with one
+                // wave per SIMD nothing else fills their latency.  Every chain operation sits three slots behind
+                // the one it depends on (the other chain's twin and one of the off-chain operations in between).
+#define SB __builtin_amdgcn_sched_barrier(0)
+                if constexpr (NCH == 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) nS[0][u] = step(0, e8[0][u]);
+                } else {
+                static_assert(NCH <= 2, "written out for two chains");
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const double2 eA = e8[0][u], eB = e8[NCH - 1][u];
+                    const double qA = Md[0] * eA.y; SB;
+                    const double qB = Md[NCH - 1] * eB.y; SB;
+                    const double fA = fsd[0] - eA.x; SB;              // (off chain) next fs_rem
+                    const double rA = __builtin_fma(-qA, fsd[0], Md[0]); SB;
+                    const double rB = __builtin_fma(-qB, fsd[NCH - 1], Md[NCH - 1]); SB;
+                    const double fB = fsd[NCH - 1] - eB.x; SB;
+                    const double aA = __builtin_fma(rA, eA.y, qA); SB;
+                    const double aB = __builtin_fma(rB, eB.y, qB); SB;
+                    fsd[0] = fA;
+                    fsd[NCH - 1] = fB;
+                    double vA = aA * eA.x; SB;
+                    double vB = aB * eB.x; SB;
+                    vA = 0.5 + vA; SB;
+                    vB = 0.5 + vB; SB;
+                    vA = __builtin_fmax(vA, 1.0); SB;  // (u32)v == 0 -> 1 (ans_util.hpp:86)
+                    vB = __builtin_fmax(vB, 1.0); SB;
+                    const double sA = __builtin_trunc(vA); SB;
+                    const double sB = __builtin_trunc(vB); SB;
+                    Md[0] = Md[0] - sA; SB;
+                    Md[NCH - 1] = Md[NCH - 1] - sB; SB;
+                    mx[0] = __builtin_fmax(mx[0], sA); SB;
+                    mx[NCH - 1] = __builtin_fmax(mx[NCH - 1], sB); SB;
+                    nS[0][u] = (u32)sA; SB;
+                    nS[NCH - 1][u] = (u32)sB; SB;
+                }
+                }
+#undef SB
+            } else {
+#pragma unroll
+                for (u32 c = 0; c < NCH; c++)
+                    if (j0 < lim[c]) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (j0 + u < lim[c]) nS[c][u] = step(c, e8[c][u]);
+                    }
             }
-            if (j0 < lim)  // (values above 65535 end in the u16 exit and are never read: the low halves are stored)
-                sp[(u64)((c0 + j0) >> 3) * NT] = make_uint4((nS[0] & 0xFFFFu) | (nS[1] << 16), (nS[2] & 0xFFFFu) | (nS[3] << 16),
-                    (nS[4] & 0xFFFFu) | (nS[5] << 16), (nS[6] & 0xFFFFu) | (nS[7] << 16));
+#pragma unroll
+            for (u32 c = 0; c < NCH; c++)
+                if (j0 < lim[c])  // (values above 65535 end in the u16 exit and are never read: the low halves are stored)
+                    sp[c][(u64)((c0 + j0) >> 3) * NT] = make_uint4((nS[c][0] & 0xFFFFu) | (nS[c][1] << 16), (nS[c][2] & 0xFFFFu) | (nS[c][3] << 16),
+                        (nS[c][4] & 0xFFFFu) | (nS[c][5] << 16), (nS[c][6] & 0xFFFFu) | (nS[c][7] << 16));
         }
+#ifdef ANSX_STAMPS
+        t_loop += wall_clock64() - t_a;
+#endif
     }
-    if (!live) return;
+#ifdef ANSX_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        g_stamps[blockIdx.x * 16 + 12] = t_commit;
+        g_stamps[blockIdx.x * 16 + 13] = t_loop;
+        g_stamps[blockIdx.x * 16 + 14] = wall_clock64() - tc0;
+    }
+#endif
     // {ok, maxS}: the cross entropy of a successful candidate is k_model_finish's
-    *(uint2*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) = make_uint2((Md == 0.0) ? 1u : 0u, mx >= 4294967295.0 ? 0xFFFFFFFFu : (u32)mx);
+#pragma unroll
+    for (u32 c = 0; c < NCH; c++)
+        if (live[c])
+            *(uint2*)(attMeta + ((u64)bb[c] * ANSX_ATTEMPTS + t) * 4) =
+                make_uint2((Md[c] == 0.0) ? 1u : 0u, mx[c] >= 4294967295.0 ? 0xFFFFFFFFu : (u32)mx[c]);
 }
 
 // Cross entropy of the NT candidates of k_candidates and the stop rule over them (guard band, see the header of this

@@ -35,7 +35,7 @@ def ctx(A, oracle_built, request):
     is forced from the first call on (ANSX_NS_HINT), so every eligible encode of the suite takes the
     read-back-free path with the fast model kernels (k_candidates / k_model_finish, 8 candidate frame sizes per
     block: ANSX_T_HINT); inputs that outgrow it repeat on the discovery path.  "hinted5": the same with 5
-    candidates per block (12 blocks per wave; blocks that need a sixth repeat).  "hinted-exact": the hinted path
+    candidates per block (12 blocks per wave; blocks that need a sixth repeat) and two recurrences per lane.  "hinted-exact": the hinted path
     with the exact model kernels (ANSX_NO_FAST_MODEL).  "fused": the single LDS-resident model kernel
     (k_model_fused, opt-in) instead."""
     # Same order as bench.py: torch (which bundles its own HIP runtime) initialises the device
@@ -55,6 +55,7 @@ def ctx(A, oracle_built, request):
         c.debug_set("ANSX_T_HINT", "8")
     if request.param == "hinted5":
         c.debug_set("ANSX_T_HINT", "5")
+        c.debug_set("ANSX_CAND_CHAINS", "2")  # two recurrences per lane (what calls of > ~12 K blocks use)
     if request.param == "hinted-exact":
         c.debug_set("ANSX_NO_FAST_MODEL", "1")
     if request.param == "fused":

@@ -444,7 +444,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
     LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
-        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr);
+        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch
     // needs anyway (largest alphabet / frame), so further batches are launched only on demand.
@@ -1392,6 +1392,16 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
         if (i + 1 < nparts && h.n % h.block_ints != 0) return ANSX_ERR_FORMAT;  // only the last part may end in a partial block
         if (h.payload_offset > part_bytes[i] || h.payload_bytes > part_bytes[i] - h.payload_offset) return ANSX_ERR_FORMAT;
         if (h.payload_offset > 0xFFFFFFFFull) return ANSX_ERR_FORMAT;
+        // the kernel derives every section of a part from its header's nblocks: the header must describe exactly the
+        // layout its own geometry implies (as decode_dev checks), or a crafted part could send the copy past its buffer
+        {
+            if (h.n == 0 || h.block_ints == 0 || h.block_ints == ANSX_SINGLE_STREAM) return ANSX_ERR_FORMAT;
+            ansx_opts po = { h.block_ints, h.ckpt_interval ? h.ckpt_interval : ANSX_NO_CHECKPOINTS,
+                (h.kind & 0x100u) ? (u32)ANSX_FLAG_COMPACT_ALPHABET : 0u, 0 };
+            Plan PP;
+            if (make_plan((int)(h.kind & 0xFFu), (int)h.fidelity, (size_t)h.n, &po, &PP)) return ANSX_ERR_FORMAT;
+            if (PP.g.nblocks != h.nblocks || PP.g.nckf != h.ckpts_per_block || PP.lay.payload_off != h.payload_offset) return ANSX_ERR_FORMAT;
+        }
         D.part[i].src = d_parts[i];
         D.part[i].first_block = nblocks;
         D.part[i].pay_base = pay;
@@ -1405,9 +1415,11 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
         maxns = std::max(maxns, h.max_nsyms);
     }
     if (nblocks > 0x7FFFFFFFull) return ANSX_ERR_ARG;
-    ansx_opts o = { H[0].block_ints, H[0].ckpt_interval ? H[0].ckpt_interval : ANSX_NO_CHECKPOINTS, 0, 0 };
+    // (bit 8 of the kind word: per-block alphabet compaction -- a flag of the plan, kept in the merged header)
+    ansx_opts o = { H[0].block_ints, H[0].ckpt_interval ? H[0].ckpt_interval : ANSX_NO_CHECKPOINTS,
+        (H[0].kind & 0x100u) ? (u32)ANSX_FLAG_COMPACT_ALPHABET : 0u, 0 };
     Plan P;
-    if (make_plan((int)H[0].kind, (int)H[0].fidelity, (size_t)n, &o, &P)) return ANSX_ERR_FORMAT;
+    if (make_plan((int)(H[0].kind & 0xFFu), (int)H[0].fidelity, (size_t)n, &o, &P)) return ANSX_ERR_FORMAT;
     if (P.g.nblocks != nblocks || P.g.nckf != H[0].ckpts_per_block) return ANSX_ERR_FORMAT;
     const u64 total = P.lay.payload_off + pay;
     if (total > cap) return ANSX_ERR_CAPACITY;

@@ -316,6 +316,10 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     const u32 t0 = wv, t1 = wv + 4u;
     const chunk k0 = load_chunk(lane, t0 < NT ? t0 : 0u);
     const chunk k1 = load_chunk(lane, t1 < NT ? t1 : 0u);
+    if (B->status) {  // (k_sort_entropy: alphabet above the hint -- violation already raised)
+        if (tid == 0) B->prelude_bytes = 0;
+        return;
+    }
     for (u32 s = tid; s < cap; s += 256) frq[s] = 0;  // absent symbols have frequency 0
     *(double2*)(lut + 2 * tid) = l2;
     STAMP(1);

@@ -276,7 +276,7 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // the divisor of that symbol's scale_freqs step (ans_util.hpp:83), so that k_candidates can prepare its reciprocal.
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
-    ansx_blk* __restrict__ blk, u32 cap, uint2* __restrict__ pairs)
+    ansx_blk* __restrict__ blk, u32 cap, uint2* __restrict__ pairs, u32* __restrict__ gflags)
 {
     extern __shared__ u64 lds_k2a[];  // [nbig_cap] big keys (freq << 16 | sym), then the staged row
     __shared__ u32 cnt[ANSX_VMAX];
@@ -297,7 +297,16 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 #pragma unroll
     for (u32 r = 0; r < SORT_PRE; r++) hp[r] = r * 64 + lane < NSP ? h[r * 64 + lane] : 0u;
     const u32 ns = blk[b].max_sym + 1;
-    if (ns > cap) return;
+    if (ns > cap) {
+        // the block outgrew the alphabet hint this (optimistic) call is sized for: no model, no stream -- said
+        // explicitly, so that the repeat does not hang on what the later kernels make of an untouched block
+        if (lane == 0) {
+            blk[b].status = 9;
+            blk[b].resolved = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_VIOL_BIT);
+        }
+        return;
+    }
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
     uint2* oP = pairs ? pairs + (u64)b * NSP : nullptr;

@@ -98,7 +98,7 @@ typedef struct {
 
 /* 64-byte container header (little endian), see DESIGN.md section 3. */
 typedef struct {
-    uint8_t magic[8];       /* "ANSXv1\0\0"                                                    */
+    uint8_t magic[8];       /* "ANSXv2\0\0"                                                    */
     uint32_t kind;          /* ansx_kind | 0x100 if ANSX_FLAG_COMPACT_ALPHABET                  */
     uint32_t fidelity;
     uint64_t n;             /* total ints                                                       */

@@ -487,6 +487,47 @@ def test_native_merge_equals_whole_encode(A, ctx, kind, f, block, ckpt, world):
             ctx.merge_containers_dev(ptrs[::-1], sizes[::-1], out.data_ptr(), out.numel())
 
 
+def test_native_merge_of_compacted_containers_and_bad_parts(A, ctx):
+    """Containers with per-block alphabet compaction (kind word | 0x100: ANSint, ANSfold + compact) merge like the
+    others; a part whose header does not describe its own layout (block count, payload offset) is refused
+    before the kernel derives section sizes from it."""
+    torch = pytest.importorskip("torch")
+    from ans_large_alphabet_amd import dist as adist
+
+    for codec, block in ((A.ANSint(ctx=ctx, block_ints=8192, ckpt_interval=1024), 8192),
+                         (A.ANSfold(1, ctx=ctx, block_ints=4096, ckpt_interval=512, compact=True), 4096)):
+        n = 11 * block + 123
+        data = ol.gen_inputs("zipf20s1.2", n, seed=29)
+        bufs, ptrs, sizes, conts = [], [], [], []
+        for r in range(3):
+            lo, cnt = adist.shard_blocks(n, block, r, 3)
+            c = codec.encode(data[lo:lo + cnt])
+            t = torch.zeros(c.size + 64, dtype=torch.uint8, device="cuda")
+            t[:c.size] = torch.from_numpy(c.copy()).cuda()
+            bufs.append(t)
+            conts.append(c)
+            ptrs.append(t.data_ptr())
+            sizes.append(c.size)
+        whole = codec.encode(data)
+        out = torch.zeros(whole.size + 4096, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        nb = ctx.merge_containers_dev(ptrs, sizes, out.data_ptr(), out.numel())
+        torch.cuda.synchronize()
+        assert nb == whole.size and np.array_equal(out[:nb].cpu().numpy(), whole)
+        pym = adist.merge_containers(torch.cat([torch.from_numpy(c.copy()) for c in conts]), sizes).numpy()
+        assert np.array_equal(pym, whole)  # the Python merge agrees
+        # header fields the kernel would trust: nblocks (offset 32) + 1, payload_offset (offset 56) + 8
+        for off, delta in ((32, 1), (56, 8)):
+            bad = conts[1].copy()
+            v = int(bad[off:off + 4].view("<u4")[0]) + delta
+            bad[off:off + 4] = np.frombuffer(np.uint32(v).tobytes(), dtype=np.uint8)
+            tb = torch.zeros(bad.size + 64, dtype=torch.uint8, device="cuda")
+            tb[:bad.size] = torch.from_numpy(bad).cuda()
+            torch.cuda.synchronize()
+            with pytest.raises(A.AnsxError):
+                ctx.merge_containers_dev([ptrs[0], tb.data_ptr(), ptrs[2]], sizes, out.data_ptr(), out.numel())
+
+
 def test_corrupted_payload_never_faults(A, ctx):
     """Random byte corruption anywhere in the container: the decoder must either report
     ANSX_ERR_FORMAT or return (wrong) data — never fault — and the context stays usable."""

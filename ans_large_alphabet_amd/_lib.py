@@ -44,7 +44,7 @@ class ContainerHeader(C.Structure):
 
 class EncodeStats(C.Structure):
     _fields_ = [("max_nsyms", C.c_uint32), ("max_log2_frame", C.c_uint32), ("near_threshold_decisions", C.c_uint32),
-                ("path", C.c_uint32)]
+                ("path", C.c_uint32), ("host_redecided", C.c_uint32)]
 
 
 class KernelTime(C.Structure):

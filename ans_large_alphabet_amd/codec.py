@@ -56,7 +56,7 @@ class Context:
         return nb.value
 
     def last_encode_stats(self):
-        """dict(max_nsyms, max_log2_frame, near_threshold_decisions, path) of the most recent encode."""
+        """dict(max_nsyms, max_log2_frame, near_threshold_decisions, path, host_redecided) of the most recent encode."""
         st = L.EncodeStats()
         L.lib().ansx_last_encode_stats(self._h, C.byref(st))
         return {k: int(getattr(st, k)) for k, _ in L.EncodeStats._fields_}

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,13 +49,15 @@ struct ansx_ctx {
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
-        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i, sizes;
+        stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i, sizes, nearlist, force;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
     // Largest alphabet (max_sym + 1) seen per (kind, fidelity, block_ints): sizes the LDS of the fused
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
     std::map<u64, u32> ns_hint;
     std::map<u64, u32> rf_hint;  // rfold: most distinct values per block seen per geometry (optimistic hash-table size)
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
+    const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
+    const u32* cur_src = nullptr;    // set by encode_general: the ints the model kernels saw (the input, or its remapped form)
     bool used_fast = false;      // set by encode_general: the call's model came from k_candidates / k_model_finish
     u32 cur_nt = 0;              // set by encode_dev: candidates per block for the fast model path of this call (0 = exact path)
     u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
@@ -78,6 +81,8 @@ struct ansx_ctx {
         u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
         u32 t_hint = 0;               // ANSX_T_HINT: candidates per block for every call (0 = learn per geometry)
         bool no_fast_model = false;   // ANSX_NO_FAST_MODEL: optimistic calls keep the exact model kernels
+        double near_band = ANSX_NEAR_BAND;  // ANSX_NEAR_BAND: relative band around the stop-rule threshold inside which the host decides (tests widen it)
+        bool near_flip = false;       // ANSX_TEST_NEAR_FLIP: the device decides close calls the wrong way (tests: the host must fix them)
         u32 cand_chains = 0;          // ANSX_CAND_CHAINS: 1 | 2 recurrences per lane in k_candidates (0 = by the call's size)
         double fast_guard = ANSX_FAST_GUARD;  // ANSX_FAST_GUARD: relative guard band of the fast model path's stop rule (tests widen it)
     } dbg;
@@ -357,6 +362,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // padding are defined to be zero, so equal inputs give byte-identical containers
     if (!P.plain) HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
 
+    if ((rc = ensure(c, c->nearlist, (size_t)ANSX_NEAR_CAP * 4))) return rc;
     const u32* src = d_in;
     const u32* mostfreq = nullptr;
     if (g.kind == ANSX_RFOLD) {
@@ -401,6 +407,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (u64)scr_stride, pa_small ? pa_uqcap : (u32)ANSX_PA_MAX_BLOCK);
         src = (const u32*)c->mapped.p;
     }
+    c->cur_src = src;
     // K1
     u32 chunk = g.block_ints < 16384u ? g.block_ints : 16384u;
     if (chunk & 3u) chunk = (chunk + 3u) & ~3u;
@@ -505,7 +512,8 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             g.block_ints <= 65535u ? 1u : 0u);
         LAUNCH(c, "k_select_model", k_select_model, NB, 64, 0, s, g, NSP, batch, hist,
             (const u16*)c->attS.p, (const u32*)c->attMeta.p, (u16*)c->prevS.p, blk,
-            (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u, always16);
+            (ansx_enc_entry*)c->table.p, (u32*)c->tab32.p, gflags, batch == nbatch - 1 ? 1u : 0u, always16,
+            (u32*)c->nearlist.p, c->cur_force, c->dbg.near_band, c->dbg.near_flip ? 1u : 0u);
         if (optimistic) {  // checked after the fact (blocks left undecided carry no model and are skipped)
             max_logM = 16;
             max_ns = ns_cap;
@@ -775,6 +783,144 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     return ANSX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Close calls of the frame-size stop rule, decided again on the host.  The reference compares
+// XH = -sum p log2(S/M) with 1.001 H (ans_util.hpp:127-128,149) using libm's log2; the device uses its own
+// portable log2 (<= 1 ulp apart), so a comparison whose two sides agree to ~1e-12 is the one place where the
+// two could part.  k_select_model lists the blocks with such a comparison; for each of them the host reads the
+// block back, rebuilds its histogram and runs adjust_freqs as written (ans_util.hpp:100-157, util.hpp:271-298;
+// this TU is compiled with -ffp-contract=off, log2 is the host libm's -- the function the reference itself
+// would call here).  If any decision differs from the device's, the call is repeated on the exact path with
+// the host's frames forced for those blocks.
+// Returns log2 of the frame size, or -1 for the reference's degenerate exit.
+int host_adjust_freqs(const std::vector<u32>& freqs, u32 largest_sym, bool require_u16)
+{
+    const u32 ns = largest_sym + 1;
+    u64 n = 0;
+    u32 sigma = 0;
+    for (u32 i = 0; i < ns; i++) {
+        n += freqs[i];
+        sigma += freqs[i] != 0;
+    }
+    if (sigma == 0) return -1;
+    u32 lg = (sigma & (sigma - 1)) == 0 ? 31u - (u32)__builtin_clz(sigma) : 32u - (u32)__builtin_clz(sigma);  // :109-112
+    std::vector<u32> order;
+    order.reserve(sigma);
+    for (u32 i = 0; i < ns; i++)
+        if (freqs[i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return freqs[a] < freqs[b]; });  // (freq, sym) ascending, :114-122
+    double H;
+    {  // util.hpp:271-282
+        double acc = 0.0;
+        for (u32 i = 0; i < ns; i++)
+            if (freqs[i]) {
+                const double p = (double)freqs[i] / (double)n;
+                acc = acc + p * std::log2(p);
+            }
+        H = -acc;
+    }
+    const double thr = H * (1.0 + (double)1 / (double)1000);  // :124,127-128
+    std::vector<u32> scaled(ns, 0u);
+    int prev = -1;
+    for (; lg <= 31; lg++) {
+        i64 Mr = (i64)1 << lg;
+        u64 fr = n;
+        for (u32 j = 0; j < sigma; j++) {  // :77-95
+            const u32 sym = order[j];
+            const double a = (double)Mr / (double)fr;
+            double v = a * (double)freqs[sym];
+            v = 0.5 + v;
+            u32 S = (u32)v;
+            if (S == 0) S = 1;
+            scaled[sym] = S;
+            Mr -= S;
+            fr -= freqs[sym];
+            if (Mr < 0) break;
+        }
+        if (Mr != 0) continue;  // :131-135
+        u32 maxS = 0;
+        for (u32 i = 0; i < ns; i++)
+            if (freqs[i] && scaled[i] > maxS) maxS = scaled[i];
+        if (require_u16 && maxS >= ANSX_U16_LIMIT) return prev;  // :141-145
+        double XH;
+        {  // util.hpp:284-298 (note the int accumulators there)
+            double acc = 0.0;
+            const double nd = (double)(int)n, md = (double)(int)((i64)1 << lg);
+            for (u32 i = 0; i < ns; i++)
+                if (freqs[i] && scaled[i]) {
+                    const double p = (double)freqs[i] / nd;
+                    const double q = (double)scaled[i] / md;
+                    acc = acc + p * std::log2(q);
+                }
+            XH = -acc;
+        }
+        if (XH < thr) return (int)lg;  // :149
+        prev = (int)lg;
+    }
+    return -1;
+}
+
+int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes, hipStream_t s,
+    u32* seen_ns, u32 ns_cap);
+
+int resolve_near(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes, hipStream_t s,
+    u32* seen_ns, u32* redecided)
+{
+    const ansx_geo& g = P.g;
+    const u32 nn = c->h_pin[ANSX_G_NEAR];
+    std::vector<u32> list;
+    if (nn <= ANSX_NEAR_CAP) {
+        list.resize(nn);
+        HIPCHK(c, hipMemcpyAsync(list.data(), c->nearlist.p, (size_t)nn * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    } else {  // more close calls than the device lists: every block is looked at
+        list.resize(g.nblocks);
+        for (u32 b = 0; b < g.nblocks; b++) list[b] = b;
+    }
+    std::vector<u32> hin, hist;
+    std::vector<u32> force;
+    u32 nre = 0;
+    for (const u32 b : list) {
+        if (b >= g.nblocks) continue;
+        const u32 nb = geo_block_n(g, b);
+        ansx_blk hb;
+        hin.resize(nb);
+        HIPCHK(c, hipMemcpyAsync(hin.data(), c->cur_src + (u64)b * g.block_ints, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&hb, (const ansx_blk*)c->blk.p + b, sizeof(hb), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (hb.pa_sigma == 1) continue;  // (compaction: a one-value block has no model)
+        hist.assign(P.NSP, 0u);
+        u32 largest = 0;
+        for (u32 i = 0; i < nb; i++) {
+            const u32 x = hin[i];
+            const u32 k = map_nbytes(g.map, x);
+            const u32 sym = map_sym(g.map, x, k);
+            if (sym >= P.NSP) return ANSX_ERR_DOMAIN;
+            hist[sym]++;
+            largest = sym > largest ? sym : largest;
+        }
+        const int lg = host_adjust_freqs(hist, largest, g.kind != ANSX_INT);
+        const int dev = hb.status ? -1 : (int)hb.logM;
+        if (lg != dev) {
+            if (force.empty()) force.assign(g.nblocks, 0u);
+            force[b] = lg < 0 ? 0xFFFFFFFFu : (u32)lg;
+            nre++;
+        }
+    }
+    *redecided = nre;
+    if (nre == 0) return ANSX_OK;
+    int rc;
+    if ((rc = ensure(c, c->force, (size_t)g.nblocks * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->force.p, force.data(), (size_t)g.nblocks * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // (force is a local)
+    c->cur_force = (const u32*)c->force.p;
+    c->cur_rf_slots = 0;
+    c->cur_pa_distinct = 0;
+    rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, seen_ns, 0);
+    c->cur_force = nullptr;
+    return rc;
+}
+
 int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes,
     hipStream_t s)
 {
@@ -815,10 +961,15 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
+    // close calls of the stop rule (counted by the exact kernels only; the fast path repeats on them): the host decides
+    u32 redecided = 0;
+    const u32 near_blocks = c->h_pin[ANSX_G_NEAR];  // (a forced repeat skips the rule for the blocks it forces)
+    if (rc == ANSX_OK && near_blocks != 0) rc = resolve_near(c, P, d_in, d_out, cap, out_bytes, s, &seen, &redecided);
+    c->last.host_redecided = redecided;
     c->last.path = path;
     c->last.max_nsyms = c->h_pin[ANSX_G_MAXNSYMS];
     c->last.max_log2_frame = c->h_pin[ANSX_G_MAXLOGM];
-    c->last.near_threshold_decisions = c->h_pin[ANSX_G_NEAR];
+    c->last.near_threshold_decisions = near_blocks;
     if (rc == ANSX_OK && !P.plain) {
         // a miss raises the hint past what was seen, so inputs whose alphabets creep upwards do not
         // miss on every call
@@ -1175,7 +1326,7 @@ int ansx_init(int device, ansx_ctx** out)
         return ANSX_ERR_HIP;
     }
     static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN", "ANSX_PARSE_FAST",
-        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD", "ANSX_CAND_CHAINS" };
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD", "ANSX_CAND_CHAINS", "ANSX_NEAR_BAND", "ANSX_TEST_NEAR_FLIP" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
@@ -1230,6 +1381,8 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NS_HINT")) c->dbg.ns_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
+    else if (!strcmp(name, "ANSX_NEAR_BAND")) c->dbg.near_band = (value && value[0]) ? strtod(value, nullptr) : ANSX_NEAR_BAND;
+    else if (!strcmp(name, "ANSX_TEST_NEAR_FLIP")) c->dbg.near_flip = on;
     else if (!strcmp(name, "ANSX_CAND_CHAINS")) {
         const u32 v = value ? (u32)strtoul(value, nullptr, 10) : 0u;
         if (v > 2) return ANSX_ERR_ARG;
@@ -1246,7 +1399,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes, &c->nearlist, &c->force };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& r : c->recs) {

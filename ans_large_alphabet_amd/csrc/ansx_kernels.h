@@ -62,12 +62,15 @@ enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
 // log2 is libm's there and ansx_log2_portable here (<= 1 ulp apart), so the decision XH < H * 1.001
 // (ans_util.hpp:149) could differ when the two sides agree to ~15 digits.  Every such comparison is
 // counted (expected: none, ever -- the sums differ by ~1e-3 relative or more in practice) and reported
-// through ansx_last_encode_stats, so a flip cannot go unnoticed.
-__device__ __forceinline__ bool ansx_near_threshold(double XH, double thr)
+// through ansx_last_encode_stats; the blocks concerned are listed for the host, which decides them again with
+// libm's log2 (resolve_near in ansx.hip) and, should it ever disagree, repeats the call with its decisions forced.
+#define ANSX_NEAR_BAND 1e-12
+#define ANSX_NEAR_CAP 1024u  // blocks with a close call the device lists for the host (more: the host looks at every block)
+__device__ __forceinline__ bool ansx_near_threshold(double XH, double thr, double band = ANSX_NEAR_BAND)
 {
     // (a single-symbol block has H = XH = 0 exactly on both sides -- log2(1) -- and is not a close call)
     const double d = XH - thr;
-    return thr > 0.0 && (d < 0 ? -d : d) <= 1e-12 * thr;
+    return thr > 0.0 && (d < 0 ? -d : d) <= band * thr;
 }
 enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 
@@ -709,8 +712,12 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
 __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 batch,
     const u32* __restrict__ hist, const u16* __restrict__ attS, const u32* __restrict__ attMeta,
     u16* __restrict__ prevS, ansx_blk* __restrict__ blk, ansx_enc_entry* __restrict__ table,
-    u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch, u32 always16)
+    u32* __restrict__ tab32, u32* __restrict__ gflags, u32 last_batch, u32 always16,
+    u32* __restrict__ nearlist, const u32* __restrict__ force, double near_band, u32 test_flip)
 {
+    // nearlist: blocks with a comparison inside near_band of its threshold (at most ANSX_NEAR_CAP listed; gflags
+    // counts them all).  force: per-block log2 frame decided by the host for such blocks (0 = none): taken as is.
+    // test_flip (tests): a close call is decided the WRONG way, so that the host's re-decision has something to fix.
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
@@ -724,7 +731,8 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     // all candidates' results in one round trip (lane t holds attempt t), then the sequential rule
     uint4 mt = make_uint4(0u, 0u, 0u, 0u);
     if (lane < ANSX_ATTEMPTS) mt = *(const uint4*)(attMeta + ((u64)b * ANSX_ATTEMPTS + lane) * 4);
-    for (u32 t = 0; t < ANSX_ATTEMPTS; t++) {
+    const u32 forced = force != nullptr ? force[b] : 0u;
+    for (u32 t = 0; t < ANSX_ATTEMPTS && !forced; t++) {
         const u32 m0 = __shfl(mt.x, (int)t), m1 = __shfl(mt.y, (int)t);
         const u32 m2 = __shfl(mt.z, (int)t), m3 = __shfl(mt.w, (int)t);
         if (!m0) continue;  // scale_freqs failed: M *= 2 (ans_util.hpp:131-135)
@@ -734,14 +742,23 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             break;
         }
         const double XH = ansx_bits_to_f64((u64)m2 | ((u64)m3 << 32));
-        near += ansx_near_threshold(XH, thr) ? 1u : 0u;
-        if (XH < thr) {  // ans_util.hpp:149
+        const bool close = ansx_near_threshold(XH, thr, near_band);
+        near += close ? 1u : 0u;
+        if ((XH < thr) != (close && test_flip != 0)) {  // ans_util.hpp:149
             chosen = (int)T;
             break;
         }
         prev = (int)T;
     }
-    if (lane == 0 && near) atomicAdd(&gflags[ANSX_G_NEAR], near);
+    if (forced) {  // the host's decision for this block: the candidate with that frame, once its batch is here
+        const int Tf = (int)forced - (int)B->m0_log2;
+        if (forced == 0xFFFFFFFFu) chosen = -1;  // (the reference's degenerate exit)
+        else if (Tf >= (int)(batch * ANSX_ATTEMPTS) && Tf < (int)((batch + 1) * ANSX_ATTEMPTS)) chosen = Tf;
+    }
+    if (lane == 0 && near) {
+        const u32 i = atomicAdd(&gflags[ANSX_G_NEAR], 1u);
+        if (i < ANSX_NEAR_CAP) nearlist[i] = b;
+    }
     if (chosen == -2) {
         // still undecided after this batch: remember the last rejected success
         if (prev >= (int)(batch * ANSX_ATTEMPTS)) {

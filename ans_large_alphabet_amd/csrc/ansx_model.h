@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
                 break;
             }
             const double XH = ansx_bits_to_f64((u64)sh_meta[t][2] | ((u64)sh_meta[t][3] << 32));
-            if (tid == 0 && ansx_near_threshold(XH, thr)) atomicAdd(&gflags[ANSX_G_NEAR], 1u);
+            if (tid == 0 && ansx_near_threshold(XH, thr)) atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_VIOL_BIT);  // a close call: the exact path (and the host) decide
             if (XH < thr) {  // ans_util.hpp:149
                 chosen = T;
                 break;

@@ -169,8 +169,11 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *   near_threshold_decisions  frame-size stop-rule comparisons XH < 1.001 H (ans_util.hpp:149) whose two sides
  *                             agreed to 1e-12 relative.  The reference evaluates log2 with libm, this library
  *                             with its own portable log2 (<= 1 ulp apart): such a comparison is the only place
- *                             where the two could decide differently.  Expected to be 0, always; a non-zero
- *                             value marks an output whose bit-parity with the reference is not guaranteed.
+ *                             where the two could decide differently.  Expected to be 0, always.  Blocks with
+ *                             such a comparison are decided again on the host with libm's log2 (the reference's
+ *                             own arithmetic, ans_util.hpp:100-157), and if the host disagrees the call is
+ *                             repeated with its decision forced: parity does not rest on this being 0.
+ *   host_redecided            blocks whose frame size the host's re-decision changed (expected 0)
  *   path                      0 discovery (alphabet size read back mid-call), 1 launched back to back on the
  *                             context's hints for this geometry (largest alphabet; for ANSrfold and the
  *                             compaction layer also the most distinct values a block had, which sizes their
@@ -182,6 +185,7 @@ typedef struct {
     uint32_t max_log2_frame;
     uint32_t near_threshold_decisions;
     uint32_t path;
+    uint32_t host_redecided;
 } ansx_encode_stats;
 int ansx_last_encode_stats(const ansx_ctx* ctx, ansx_encode_stats* out);
 
@@ -204,7 +208,10 @@ int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t fir
  * ("ring" | "staged" | ""), ANSX_DECODE_TABLE, ANSX_NO_STREAM_LDS, ANSX_PARSE_GENERIC, ANSX_PARSE_WIN, ANSX_PARSE_FAST,
  * ANSX_PARSE_STAGE_WORDS (number), ANSX_ENCODE_GTAB16, ANSX_TEST_TABLE16_FIXUP, ANSX_MODEL_FUSED, ANSX_MODEL_SYNC,
  * ANSX_NS_HINT (number: alphabet-size hint for every call instead of the per-geometry one the context
- * learns; too small a value only costs a repeat on the general path)
+ * learns; too small a value only costs a repeat on the general path), ANSX_T_HINT (number: candidate frame sizes per
+ * block of the fast model path), ANSX_NO_FAST_MODEL, ANSX_FAST_GUARD / ANSX_NEAR_BAND (numbers: relative bands around
+ * the stop-rule threshold inside which the fast path repeats on the exact one / the host re-decides),
+ * ANSX_TEST_NEAR_FLIP (the device decides close calls the wrong way), ANSX_CAND_CHAINS (1 | 2)
  * (flags: "1" on, "0"/""/NULL off).  Unknown name: ANSX_ERR_ARG. */
 int ansx_debug_set(ansx_ctx* ctx, const char* name, const char* value);
 

@@ -889,6 +889,38 @@ def test_fast_model_path_and_its_repeats(A, oracle_built):
         c.close()
 
 
+@pytest.mark.parametrize("kind,f", [(ol.FOLD, 1), (ol.RFOLD, 1), (ol.FOLD, 3), (ol.MSB, 0)])
+def test_close_calls_are_decided_again_on_the_host(A, oracle_built, kind, f):
+    """The stop rule XH < 1.001 H (ans_util.hpp:149) is evaluated with a portable log2 on the device and with libm's
+    in the reference.  Blocks with a comparison inside ANSX_NEAR_BAND of its threshold (1e-12; none ever occurs) are
+    decided again on the host with libm, and a differing decision is forced in a repeat of the call.  Here the band
+    is widened so that such blocks exist, and then the device is made to decide them the WRONG way: the bytes must
+    still be the oracle's."""
+    n = 7 * 16384 + 1234
+    data = ol.gen_inputs("zipf20s1.2", n, seed=61)
+    if kind == ol.RFOLD:
+        data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    c = A.Context(0)
+    codec = codec_for(A, c, kind, f, block_ints=16384, ckpt_interval=1024)
+    ref = codec.encode(data)
+    st = c.last_encode_stats()
+    assert st["near_threshold_decisions"] == 0 and st["host_redecided"] == 0
+    check_container(A, ref, data, kind, f, 16384, 1024)
+    c.debug_set("ANSX_NO_FAST_MODEL", "1")   # (the fast model kernels repeat on the exact ones for anything within 1e-9)
+    c.debug_set("ANSX_NEAR_BAND", "2e-2")
+    again = codec.encode(data)
+    st = c.last_encode_stats()
+    assert st["near_threshold_decisions"] > 0 and st["host_redecided"] == 0, st  # the host agrees with the device
+    assert np.array_equal(again, ref)
+    c.debug_set("ANSX_TEST_NEAR_FLIP", "1")
+    fixed = codec.encode(data)
+    st = c.last_encode_stats()
+    assert st["near_threshold_decisions"] > 0 and st["host_redecided"] > 0, st  # ... and overrules it when it must
+    assert np.array_equal(fixed, ref)
+    assert np.array_equal(codec.decode(fixed, n), data)
+    c.close()
+
+
 def test_fused_model_many_geometries(A, oracle_built):
     """Fused path over block sizes / lengths incl. partial and tiny blocks, constant blocks (16 frame
     sizes: more than one candidate batch) and blocks that take the reference's degenerate exits."""

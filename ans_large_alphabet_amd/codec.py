@@ -232,6 +232,17 @@ def generate_host(spec, n, seed=0, first_index=0):
     return out
 
 
+def zipf_from_uniform(n, q, u01):
+    """(value, accepted) of one pass of the Zipf generator's rejection loop for the canonical uniform u01."""
+    import ctypes as C
+
+    k, acc = C.c_uint32(0), C.c_int(0)
+    st = L.lib().ansx_zipf_from_uniform(float(n), float(q), float(u01), C.byref(k), C.byref(acc))
+    if st != L.OK:
+        raise L.AnsxError(st, "ansx_zipf_from_uniform")
+    return int(k.value), bool(acc.value)
+
+
 def generate_dev(ctx, spec, out_ptr, n, seed=0, first_index=0, stream=None):
     """Fill device memory at out_ptr (n x uint32) with the named distribution; asynchronous on `stream`."""
     dist, a, b = parse_dist(spec)

@@ -1724,6 +1724,16 @@ int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t fir
     return ANSX_OK;
 }
 
+int ansx_zipf_from_uniform(double n, double q, double u01, uint32_t* k, int* accepted)
+{
+    if (!k || !accepted || !(u01 >= 0.0 && u01 <= 1.0)) return ANSX_ERR_ARG;
+    ansx_gen_params P;
+    int rc = gen_setup(ANSX_GEN_ZIPF, n, q, 0, &P);
+    if (rc) return rc;
+    *accepted = gen_zipf_try(P, u01, k) ? 1 : 0;
+    return ANSX_OK;
+}
+
 int ansx_selftest_log2(ansx_ctx* c, const double* in, double* out, size_t n)
 {
     if (!c || !in || !out || n == 0) return ANSX_ERR_ARG;

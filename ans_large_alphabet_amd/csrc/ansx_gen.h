@@ -124,6 +124,22 @@ ANSX_HD void gen_prepare(ansx_gen_params* P)
     }
 }
 
+// One pass of the rejection loop of zipf_dist.hpp:49-59 for the canonical uniform u01 (the reference maps it to
+// [H(x1), H(n)) the same way: libstdc++'s uniform_real_distribution is u01 * (b - a) + a): candidate value and
+// whether it is accepted.  tests/test_generators.py checks this map against the reference class itself, driven by
+// the same uniforms (oracle/ref_shim.cpp::ref_zipf_trace, tests/golden/zipf_trace.json).
+ANSX_HD bool gen_zipf_try(const ansx_gen_params& P, double u01, u32* k_out)
+{
+    const double n = P.a, q = P.b, omq = P.c2;
+    const double u = P.c0 + u01 * (P.c1 - P.c0);
+    const double x = gen_zipf_Hinv(u, omq);
+    double kr = __builtin_floor(x + 0.5);  // std::round for positive x
+    kr = kr < 1.0 ? 1.0 : (kr > n ? n : kr);
+    *k_out = (u32)kr;
+    const double hk = gen_exp(-q * gen_log(kr));  // h(k) = k^-q, zipf_dist.hpp:102
+    return u >= gen_zipf_H(kr + 0.5, omq) - hk;
+}
+
 ANSX_HD u32 gen_value(const ansx_gen_params& P, u64 index)
 {
     if (P.dist == ANSX_GEN_UNIFORM) {
@@ -139,17 +155,9 @@ ANSX_HD u32 gen_value(const ansx_gen_params& P, u64 index)
     }
     // zipf over {1..n} with exponent q: rejection-inversion (zipf_dist.hpp:49-59); the loop is bounded so
     // that a device lane always terminates (the acceptance rate is above 80 %)
-    const double n = P.a, q = P.b, omq = P.c2;
     u32 k = 1;
-    for (u32 draw = 0; draw < 64; draw++) {
-        const double u = P.c0 + gen_u01(gen_mix(P.seed, index, draw)) * (P.c1 - P.c0);
-        const double x = gen_zipf_Hinv(u, omq);
-        double kr = __builtin_floor(x + 0.5);  // std::round for positive x
-        kr = kr < 1.0 ? 1.0 : (kr > n ? n : kr);
-        k = (u32)kr;
-        const double hk = gen_exp(-q * gen_log(kr));  // h(k) = k^-q, zipf_dist.hpp:102
-        if (u >= gen_zipf_H(kr + 0.5, omq) - hk) break;
-    }
+    for (u32 draw = 0; draw < 64; draw++)
+        if (gen_zipf_try(P, gen_u01(gen_mix(P.seed, index, draw)), &k)) break;
     return k;
 }
 

@@ -119,6 +119,116 @@ def cpu_baseline(sample, kind, f, block_ints=16384, budget_s=12.0):
     }
 
 
+def all_cores_baseline(sample, kind, f, block_ints, budget_s=10.0):
+    """The reference CPU path on every host core this process may use: blocks are independent encode() calls
+    (SURVEY 8d "optional all-cores row"), one Python thread per core, each calling into oracle/_ref (ctypes releases
+    the GIL).  Like-for-like with the GPU run: the same block size.  Bounded: stops handing out blocks when the
+    budget is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import oracle_lib as ol
+
+    if not ol.have_ref():
+        return None
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    parts = [np.ascontiguousarray(sample[a:a + block_ints]) for a in range(0, sample.size, block_ints)]
+    # size the sample to the budget from one timed block
+    t0 = time.perf_counter()
+    s0 = ol.ref_encode(kind, f, parts[0])
+    ol.ref_decode(kind, f, s0, parts[0].size)
+    per_block = max(time.perf_counter() - t0, 1e-6)
+    take = int(min(len(parts), max(cores, budget_s * cores / per_block / 2)))
+    parts = parts[:take]
+    n = sum(p_.size for p_ in parts)
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        t0 = time.perf_counter()
+        streams = list(ex.map(lambda p_: ol.ref_encode(kind, f, p_), parts))
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        backs = list(ex.map(lambda sp: ol.ref_decode(kind, f, sp[0], sp[1].size), zip(streams, parts)))
+        t_dec = time.perf_counter() - t0
+    ok = all(np.array_equal(b_, p_) for b_, p_ in zip(backs, parts))
+    return {"value": n / (t_enc + t_dec) / 1e6, "unit": "Mints/s", "cores": cores, "kind": "reference", "block_ints": block_ints,
+            "ints": n, "enc_mints": n / t_enc / 1e6, "dec_mints": n / t_dec / 1e6, "roundtrip_ok": ok,
+            "sample": "first %d ints of the workload in %d blocks, one Python thread per core over oracle/_ref" % (n, len(parts))}
+
+
+def gpu_enc_dec_rates(torch, codec, d_in, n, d_out, cap, d_back, stream, runs=5):
+    """GPU encode and decode rates the way the reference's harness times a codec (table_efficiency.cpp:32,78-101:
+    NUM_RUNS = 5, minimum kept), with events around the whole encode (histogram + model + prelude + encode + container)
+    and the whole decode, data resident in HBM."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    best_e = best_d = 1e30
+    for i in range(runs + 1):  # (the first pass is a warm-up)
+        ev[0].record()
+        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+        ev[1].record()
+        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if i:
+            best_e = min(best_e, ev[0].elapsed_time(ev[1]))
+            best_d = min(best_d, ev[1].elapsed_time(ev[2]))
+    return {"enc_mints": n / best_e / 1e3, "dec_mints": n / best_d / 1e3, "enc_ms": best_e, "dec_ms": best_d,
+            "combined_mints": n / (best_e + best_d) / 1e3,
+            "policy": "events around the full encode / full decode, minimum of %d runs after one warm-up "
+                      "(table_efficiency.cpp:32,78-101), data resident in HBM" % runs}
+
+
+def host_buffer_rates(codec, sample, runs=3):
+    """The host-buffer entry points (ansx_encode / ansx_decode: H2D + device path + D2H through pageable memory):
+    the PCIe-inclusive rate, never the headline value."""
+    import numpy as np
+
+    best_e = best_d = 1e30
+    cont = None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        cont = codec.encode(sample)
+        best_e = min(best_e, time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        back = codec.decode(cont, sample.size)
+        best_d = min(best_d, time.perf_counter() - t0)
+    return {"ints": int(sample.size), "enc_mints": sample.size / best_e / 1e6, "dec_mints": sample.size / best_d / 1e6,
+            "combined_mints": sample.size / (best_e + best_d) / 1e6, "roundtrip_ok": bool(np.array_equal(back, sample)),
+            "note": "ansx_encode / ansx_decode on pageable host buffers: H2D of the input, device path, D2H of the container "
+                    "(and the reverse); minimum of %d runs" % runs}
+
+
+def config1_rows(A):
+    """BASELINE config 1: ANSfold-1 on 10^6 uniform(1..256) ints through the Table-10 harnesses -- the reference's
+    loop over the reference's own codecs on the CPU (oracle/_ref/table10_cpu.x), and this package's harness
+    (tools/table_efficiency.x, host buffers, so launch latency and PCIe dominate at this size)."""
+    import tempfile
+
+    out = {"input": "uniform(1..256), 1 000 000 ints, ansx_generate_host seed %d" % SEED}
+    data = A.generate_host("uniform1-256", 1000000, seed=SEED)
+    with tempfile.TemporaryDirectory() as tmp:
+        data.tofile(os.path.join(tmp, "uniform1-256.u32"))
+        cpu = os.path.join(ROOT, "oracle", "_ref", "table10_cpu.x")
+        if os.path.exists(cpu):
+            r = subprocess.run([cpu, "-i", tmp], capture_output=True, text=True, timeout=120)
+            out["cpu_reference_rows"] = r.stdout if r.returncode == 0 else "failed: " + r.stderr[-300:]
+            out["cpu_reference_harness"] = "oracle/_ref/table10_cpu.x: src/table_efficiency.cpp's run<>() over oracle/_ref (1 thread, %s)" % _cpu_model()
+        else:
+            out["cpu_reference_rows"] = None
+        tools = os.path.join(ROOT, "ans_large_alphabet_amd", "tools")
+        exe = os.path.join(tools, "table_efficiency.x")
+        try:
+            if not os.path.exists(exe):
+                subprocess.check_call(["make", "-s", "-C", tools, "table_efficiency.x"])
+            r = subprocess.run([exe, "-i", tmp, "--bits"], capture_output=True, text=True, timeout=120)
+            out["gpu_rows"] = r.stdout if r.returncode == 0 else "failed: " + r.stderr[-300:]
+        except Exception as exc:  # noqa: BLE001
+            out["gpu_rows"] = "failed: %r" % (exc,)
+    return out
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this workload
     (profiles/*_hbm_traffic_pmc.json, one per profiled configuration: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes, gfx950
@@ -205,7 +315,7 @@ def workload_string(codec_name, f, n, spec, block, ckpt):
 
 
 def run_single(torch, A, ctx, device, codec_name, fidelity, spec, n, steps, warmup, block=0, ckpt=0, d_in=None,
-               seed=SEED, cpu_sample=0, compact=False):
+               seed=SEED, cpu_sample=0, compact=False, profile=True):
     """One single-GPU configuration: timed encode+decode steps, round trip, per-kernel pass."""
     codec = make_codec(A, ctx, codec_name, fidelity, block, ckpt, compact)
     if d_in is None:
@@ -229,8 +339,11 @@ def run_single(torch, A, ctx, device, codec_name, fidelity, spec, n, steps, warm
     stats = ctx.last_encode_stats()
     c_bytes = nb / n
     workload = workload_string(codec_name, fidelity, n, spec, block or A.DEFAULT_BLOCK_INTS, ckpt or A.DEFAULT_CKPT_INTERVAL)
-    kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
-    res = {"workload": workload, "codec": codec.name(), "distribution": spec, "ints": n, "seed": seed,
+    kernels = roofline = None
+    if profile:
+        kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
+    rates = gpu_enc_dec_rates(torch, codec, d_in, n, d_out, cap, d_back, stream, runs=5 if profile else 3)
+    res = {"workload": workload, "codec": codec.name(), "distribution": spec, "ints": n, "seed": seed, "gpu_rates": rates,
            "value": n * steps / dt / 1e6, "unit": "Mints/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
            "roundtrip_ok": ok, "bits_per_int": 8 * c_bytes, "near_threshold_decisions": stats["near_threshold_decisions"],
            "encode_path": stats["path"], "roofline": roofline, "kernels": kernels}
@@ -296,9 +409,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs rows (N = 1)")
-    ap.add_argument("--gather-root", default="fixed", choices=["fixed", "rotate"],
-                    help="N > 1: root of the per-step container gather: always rank 0 (default) or rank k mod N "
-                         "of step k (spreads the traffic over all xGMI links)")
+    ap.add_argument("--no-frontier", action="store_true", help="skip the block size / restart interval frontier rows (N = 1)")
+    ap.add_argument("--gather-root", default="auto", choices=["auto", "fixed", "rotate"],
+                    help="N > 1: root of the per-step container gather: rank k mod N of step k (rotate: spreads the "
+                         "traffic over all xGMI links), always rank 0 (fixed), or auto (default): rotate, set up and "
+                         "VERIFIED during warm-up -- one merged container per root decoded and checked against the "
+                         "generator -- with a fall-back to fixed, agreed by all ranks, on any failure")
+    ap.add_argument("--test-fail-rotate", action="store_true",
+                    help="rehearsals: the verification of the rotating root reports a mismatch on root 1, so that "
+                         "--gather-root auto exercises its fall-back")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N > 1 control-flow rehearsal on ONE GPU: gloo backend, every rank on cuda:0, "
                          "containers gathered through host copies (not a measurement)")
@@ -340,12 +459,15 @@ def main():
     # ---- synthetic input, resident in HBM: rank r holds ints [r n, (r+1) n) of ONE global list
     d_in = gen_input(torch, A, ctx, args.dist, n, SEED, device, first_index=rank * n)
     cap = min(codec.bound(n), 8 * n + (64 << 20))
-    rotate = world > 1 and args.gather_root == "rotate"
+    rotate = world > 1 and args.gather_root in ("auto", "rotate")
+    root_policy = {"requested": args.gather_root, "used": None, "fallback_reason": None}
     DEPTH = 1 if world == 1 else (min(4, max(2, world)) if rotate else 2)
     outs = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(DEPTH)]
     d_out = outs[0]
     d_back = torch.zeros(n, dtype=torch.int32, device=device)
     stream = torch.cuda.current_stream().cuda_stream
+    import datetime
+    WAIT = datetime.timedelta(seconds=180)  # every wait on a transfer is bounded: a hang exits non-zero
 
     # N > 1.  Every step ends with the rank containers concatenated into one container on a root GPU.
     # A rank's container is ~0.29 GB, i.e. several ms on one xGMI link -- longer than the step's compute
@@ -358,29 +480,52 @@ def main():
     setup_ok = 1
     if dist is not None and rotate:
         try:
-            groups = [dist.new_group(ranks=list(range(world))) for _ in range(DEPTH)]
+            groups = [dist.new_group(ranks=list(range(world)), timeout=WAIT) for _ in range(DEPTH)]
         except Exception as exc:  # noqa: BLE001
             print("bench.py rank %d: rotating-root setup failed (%r)" % (rank, exc), file=sys.stderr)
             setup_ok = 0
-    if dist is not None:
-        # a setup failure on ANY rank sends EVERY rank to the fixed root (ranks must not diverge)
-        flag = torch.tensor([setup_ok], dtype=torch.int32, device=cdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and rotate:
-            rotate = False
-            DEPTH = 2
-            outs = outs[:2]
-            groups = [None] * DEPTH
 
-    state = {"k": 0, "xfer": 0, "merged_bytes": 0}
+    state = {"k": 0, "xfer": 0, "merged_bytes": 0, "merged_root": 0}
     pending = collections.deque()  # (step, root, works, slot) of the steps still in flight
     recv = {}                      # per pipeline slot on a root: receive buffer [world][xfer]
     merged = [None]
 
+    def all_agree(flag_value):
+        """MIN over ranks of a 0/1 flag: a failure on ANY rank sends EVERY rank the same way (ranks must not diverge)."""
+        flag = torch.tensor([flag_value], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item())
+
+    def to_fixed(reason):
+        """Fall back to rank 0 as the root of every step (buffers of the rotating form are dropped)."""
+        nonlocal rotate, DEPTH, outs, groups
+        root_policy["fallback_reason"] = reason
+        rotate = False
+        DEPTH = 2
+        outs = outs[:2]
+        groups = [None] * DEPTH
+        recv.clear()
+        merged[0] = None
+        alloc_root_buffers()
+
+    def alloc_root_buffers():
+        x = state["xfer"]
+        if not x:
+            return
+        roots = range(world) if rotate else [0]
+        if rank in roots:
+            for slot in range(DEPTH):
+                recv[slot] = torch.zeros(world * x, dtype=torch.uint8, device=cdev)
+            merged[0] = torch.zeros(world * x + (1 << 20), dtype=torch.uint8, device=device)
+
+    if dist is not None and rotate and all_agree(setup_ok) == 0:
+        to_fixed("communicator setup failed on some rank")
+
     def finish_one():
         k, root, works, slot = pending.popleft()
         for w in works:
-            w.wait()
+            if not w.wait(WAIT):
+                raise SystemExit("bench.py rank %d: transfer of step %d timed out" % (rank, k))
         if rank == root and world > 1 and state["xfer"]:
             buf = recv[slot]
             x = state["xfer"]
@@ -388,6 +533,21 @@ def main():
                 buf = buf.to(device)
             ptrs = [buf.data_ptr() + r * x for r in range(world)]
             state["merged_bytes"] = ctx.merge_containers_dev(ptrs, [x] * world, merged[0].data_ptr(), merged[0].numel())
+            state["merged_root"] = root
+
+    def check_merged(root):
+        """On `root`: decode its merged container (N x n ints) and compare three rank slices with the generator's values."""
+        mine = True
+        if rank == root:
+            total = world * n
+            whole = torch.empty(total, dtype=torch.int32, device=device)
+            codec.decode_dev(merged[0].data_ptr(), state["merged_bytes"], whole.data_ptr(), total, stream=stream)
+            torch.cuda.synchronize()
+            for r in sorted(set([0, world // 2, world - 1])):
+                want = gen_input(torch, A, ctx, args.dist, n, SEED, device, first_index=r * n)
+                mine = mine and bool(torch.equal(whole[r * n:(r + 1) * n], want))
+            del whole
+        return mine
 
     def step():
         k = state["k"]
@@ -431,22 +591,40 @@ def main():
         x = int(t.item())
         x = min(cap, (x + x // 32 + 4096 + 15) // 16 * 16)
         state["xfer"] = x
-        roots = range(world) if rotate else [0]
-        if rank in roots:
-            for slot in range(DEPTH):
-                recv[slot] = torch.zeros(world * x, dtype=torch.uint8, device=cdev)
-            merged[0] = torch.zeros(world * x + (1 << 20), dtype=torch.uint8, device=device)
-        if rotate and not args.rehearse_gloo:  # establish every (communicator, root) connection before timing
-            tiny = torch.zeros(64, dtype=torch.uint8, device=device)
-            for g_ in groups:
-                for d_ in range(world):
-                    if rank == d_:
-                        ops = [dist.P2POp(dist.irecv, tiny.clone(), r, g_) for r in range(world) if r != d_]
-                    else:
-                        ops = [dist.P2POp(dist.isend, tiny, d_, g_)]
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
-            torch.cuda.synchronize()
+        alloc_root_buffers()
+        if rotate:
+            # establish every (communicator, root) connection, then one full cycle of roots with each merged
+            # container decoded and checked BEFORE the timed region; any failure on any rank -> fixed root
+            ok_flag, why = 1, None
+            try:
+                if not args.rehearse_gloo:
+                    tiny = torch.zeros(64, dtype=torch.uint8, device=device)
+                    for g_ in groups:
+                        for d_ in range(world):
+                            if rank == d_:
+                                ops = [dist.P2POp(dist.irecv, tiny.clone(), r, g_) for r in range(world) if r != d_]
+                            else:
+                                ops = [dist.P2POp(dist.isend, tiny, d_, g_)]
+                            for w in dist.batch_isend_irecv(ops):
+                                if not w.wait(WAIT):
+                                    raise RuntimeError("connection set-up timed out")
+                    torch.cuda.synchronize()
+                for _ in range(world):
+                    step()
+                    sync_all()
+                    root = (state["k"] - 1) % world
+                    if not check_merged(root) or (args.test_fail_rotate and root == 1 and rank == 1):
+                        ok_flag, why = 0, "merged container of root %d did not match the generator" % root
+            except SystemExit:
+                raise
+            except Exception as exc:  # noqa: BLE001
+                print("bench.py rank %d: rotating-root verification failed (%r)" % (rank, exc), file=sys.stderr)
+                ok_flag, why = 0, repr(exc)
+            if all_agree(ok_flag) == 0:
+                if args.gather_root == "rotate":
+                    raise SystemExit("--gather-root rotate failed its verification: %s" % why)
+                pending.clear()
+                to_fixed(why or "verification failed on another rank")
     for _ in range(max(args.warmup - 1, 1 if dist is not None else 0)):
         nb = step()
     sync_all()
@@ -464,20 +642,11 @@ def main():
     if dist is not None:
         # the root of the LAST step decodes the merged container and checks it against the generator
         last_root = ((state["k"] - 1) % world) if rotate else 0
-        mine = True
-        if rank == last_root:
-            total = world * n
-            whole = torch.empty(total, dtype=torch.int32, device=device)
-            codec.decode_dev(merged[0].data_ptr(), state["merged_bytes"], whole.data_ptr(), total, stream=stream)
-            torch.cuda.synchronize()
-            for r in sorted(set([0, world // 2, world - 1])):
-                want = gen_input(torch, A, ctx, args.dist, n, SEED, device, first_index=r * n)
-                mine = mine and bool(torch.equal(whole[r * n:(r + 1) * n], want))
-            del whole
-        mo = torch.tensor([1 if mine else 0], dtype=torch.int32, device=cdev)
+        mo = torch.tensor([1 if check_merged(last_root) else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(mo, op=dist.ReduceOp.MIN)
         merged_ok = bool(int(mo.item()))
         ok = ok and merged_ok
+        root_policy["used"] = "rotate" if rotate else "fixed"
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt / 1e6
     c_bytes = nb / n  # compressed bytes per int, everything included
@@ -489,11 +658,17 @@ def main():
     if not args.no_profile:
         kernels, roofline = kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_bytes, workload)
 
-    cpu = None
+    gpu_rates = None
+    if world == 1 and not args.no_profile:
+        gpu_rates = gpu_enc_dec_rates(torch, codec, d_in, n, d_out, cap, d_back, stream)
+
+    cpu = cpu_all = host_api = None
     if rank == 0 and world == 1 and not args.no_cpu and not args.compact and args.codec != "int":
         m = min(n, args.cpu_sample)
         sample = d_in[:m].cpu().numpy().view("uint32")
         cpu = cpu_baseline(sample, kind, args.fidelity, block_ints)
+        cpu_all = all_cores_baseline(sample, kind, args.fidelity, block_ints)
+        host_api = host_buffer_rates(codec, sample[:min(m, 64 * (1 << 20))])
 
     # ---- the other single-GPU BASELINE configs, a few steps each (N = 1 only)
     extra = None
@@ -526,6 +701,45 @@ def main():
         except Exception as exc:  # noqa: BLE001
             extra.append({"baseline_config": "config 5 fallback", "error": repr(exc)})
 
+    # ---- speed against size: block length / restart interval (the two options that decide the operating point)
+    frontier = config1 = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_frontier:
+        frontier = []
+        for blk_, ck_ in ((16384, 512), (16384, 1024), (16384, 2048), (32768, 1024)):
+            try:
+                r = run_single(torch, A, ctx, device, args.codec, args.fidelity, args.dist, n, 3, 2, block=blk_, ckpt=ck_, profile=False)
+                frontier.append({"block_ints": blk_, "ckpt_interval": ck_, "value": r["value"], "unit": "Mints/s",
+                                 "bits_per_int": r["bits_per_int"], "enc_mints": r["gpu_rates"]["enc_mints"],
+                                 "dec_mints": r["gpu_rates"]["dec_mints"], "roundtrip_ok": r["roundtrip_ok"]})
+            except Exception as exc:  # noqa: BLE001
+                frontier.append({"block_ints": blk_, "ckpt_interval": ck_, "error": repr(exc)})
+            torch.cuda.empty_cache()
+        try:
+            config1 = config1_rows(A)
+        except Exception as exc:  # noqa: BLE001
+            config1 = {"error": repr(exc)}
+
+    multi_gpu = "single GPU"
+    if world > 1:
+        # what the gather costs by arithmetic, so that a scaling record explains itself: every step moves
+        # (N - 1) containers into one root, each over its sender's own xGMI link (one hop)
+        LINK_GBS = 50.0  # assumed sustained one-direction rate of one xGMI link (peak ~64 GB/s; MI355X_MICROARCH.md: 7 links/GPU)
+        x = state["xfer"]
+        link_ms = x / (LINK_GBS * 1e9) * 1e3
+        in_flight = DEPTH - 1
+        multi_gpu = {
+            "split": "contiguous block ranges per rank (rank r draws and encodes ints [r n, (r+1) n) of one list)",
+            "gather": "per step every rank sends its container (fixed %d-byte transfers, RCCL send/recv) to the step's root, which "
+                      "merges them into one container with ansx_merge_containers_dev inside the timed step; the merged container "
+                      "of the last step is decoded on its root and checked against the generator" % x,
+            "root_policy": root_policy, "transfers_in_flight": in_flight,
+            "gather_bytes_per_step": (world - 1) * x, "gather_bytes_per_link_per_step": x,
+            "assumed_link_GBps": LINK_GBS, "predicted_link_ms": link_ms,
+            "predicted_note": ("fixed root: the root's N - 1 inbound links each carry one container per step, so a step cannot be "
+                               "shorter than max(compute, link_ms); rotating root: consecutive steps use different roots and %d "
+                               "transfers overlap, so the bound is max(compute, link_ms / %d)" % (in_flight, max(in_flight, 1))),
+            "predicted_step_ms_bound": max(link_ms / max(in_flight, 1) if rotate else link_ms, 0.0),
+        }
     if rank == 0:
         line = {
             "metric": "encode+decode Mints/s (uint32), bit-exact vs CPU reference per block",
@@ -540,16 +754,13 @@ def main():
                        "alphabet_compaction": bool(args.compact or args.codec == "int"),
                        "generator": "ansx_generate_dev (counter-based, seed %d, rank r draws indices [r n, (r+1) n))" % SEED,
                        "block_ints": block_ints, "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
-                       "multi_gpu": ("contiguous block ranges per rank; per step every rank sends its container (fixed %d-byte "
-                                     "transfers, RCCL send/recv) to %s, which merges them into one container with "
-                                     "ansx_merge_containers_dev inside the timed step (%d transfers in flight); the merged "
-                                     "container of the last step is decoded on its root and checked against the generator"
-                                     % (state["xfer"], "a root that rotates per step (k mod N)" if rotate else "rank 0", DEPTH - 1))
-                       if world > 1 else "single GPU"},
+                       "multi_gpu": multi_gpu},
             "roundtrip_ok": ok, "merged_container_ok": merged_ok,
             "compressed_bytes_per_int": c_bytes, "bits_per_int": 8 * c_bytes,
             "near_threshold_decisions": stats["near_threshold_decisions"], "encode_path": stats["path"],
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "extra_configs": extra,
+            "roofline": roofline, "cpu_baseline": cpu, "gpu_rates": gpu_rates, "cpu_all_cores": cpu_all,
+            "host_buffer_api": host_api, "kernels": kernels, "extra_configs": extra, "frontier": frontier,
+            "config1_table10": config1,
             "workspace_mb": ctx.workspace_bytes() / 1e6,
         }
         if cpu:

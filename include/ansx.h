@@ -218,6 +218,11 @@ int ansx_debug_set(ansx_ctx* ctx, const char* name, const char* value);
 /* Bytes of device workspace currently held by the context. */
 size_t ansx_workspace_bytes(const ansx_ctx* ctx);
 
+/* One pass of the Zipf generator's rejection loop for a given canonical uniform u01 in [0, 1] (unit tests: the map
+ * uniform -> value is compared with include/zipf_dist.hpp:49-59 driven by the same uniforms): candidate value *k and
+ * whether it is accepted.  Host only, no device needed. */
+int ansx_zipf_from_uniform(double n, double q, double u01, uint32_t* k, int* accepted);
+
 /* Host evaluation of the portable log2 used by the device normaliser (unit tests only). */
 double ansx_host_log2(double x);
 /* The same function evaluated on the DEVICE for n inputs (host arrays): the normaliser relies on

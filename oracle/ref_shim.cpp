@@ -29,6 +29,7 @@
 #include "ans_reorder_fold.hpp"
 #include "ans_msb.hpp"
 #include "ans_int.hpp"
+#include "zipf_dist.hpp"
 
 namespace {
 
@@ -180,6 +181,37 @@ uint32_t ref_fold_exception_bytes(int f, uint32_t s)
 {
     DISPATCH_F(ans_fold_exception_bytes, s)
     return 0;
+}
+
+
+// include/zipf_dist.hpp:49-59 driven by std::mt19937(seed) exactly as src/generate_inputs.cpp:63-79 does, with the
+// uniforms it consumed recorded: libstdc++'s uniform_real_distribution draws generate_canonical<double, 53> and
+// maps it to [H(x1), H(n)); a clone of the generator is replayed until it catches up, so u01[] holds, per output
+// value, every canonical uniform of its rejection loop (the last one is the accepted draw).
+// Returns the number of uniforms written (stops early when cap would be exceeded; *n_values = values completed).
+size_t ref_zipf_trace(uint32_t n, double q, uint32_t seed, size_t count, uint32_t* values, uint32_t* ndraws, double* u01,
+    size_t cap, size_t* n_values)
+{
+    std::mt19937 g(seed), g2(seed);
+    zipf_distribution<uint32_t> z(n, q);
+    size_t nu = 0, i = 0;
+    for (; i < count; i++) {
+        const uint32_t v = z(g);
+        uint32_t k = 0;
+        const size_t start = nu;
+        do {
+            if (nu >= cap) {
+                *n_values = i;
+                return start;
+            }
+            u01[nu++] = std::generate_canonical<double, 53>(g2);
+            k++;
+        } while (!(g2 == g));
+        values[i] = v;
+        ndraws[i] = k;
+    }
+    *n_values = i;
+    return nu;
 }
 
 } // extern "C"

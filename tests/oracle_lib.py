@@ -96,6 +96,11 @@ def _load_ref(name="libans_ref.so"):
     lib.ref_serialize_prelude.argtypes = [_u32p, C.c_size_t, C.c_uint64, _u8p]
     lib.ref_load_prelude.restype = C.c_size_t
     lib.ref_load_prelude.argtypes = [_u8p, _u32p]
+    if hasattr(lib, "ref_zipf_trace"):
+        lib.ref_zipf_trace.restype = C.c_size_t
+        lib.ref_zipf_trace.argtypes = [C.c_uint32, C.c_double, C.c_uint32, C.c_size_t, _u32p, _u32p,
+                                       np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"), C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
     if hasattr(lib, "ref_pa_encode"):
         lib.ref_pa_encode.restype = C.c_size_t
         lib.ref_pa_encode.argtypes = [C.c_int, C.c_int, _u32p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -307,3 +312,17 @@ def canonicalize(stream, info):
         w = int.from_bytes(s[end - 4:end].tobytes(), "little") & ((1 << vb) - 1)
         s[end - 4:end] = np.frombuffer(w.to_bytes(4, "little"), dtype=np.uint8)
     return s
+
+
+def ref_zipf_trace(n, q, seed, count):
+    """include/zipf_dist.hpp driven by std::mt19937(seed): (values, draws per value, canonical uniforms consumed)."""
+    lib = ref()
+    vals = np.zeros(count, dtype=np.uint32)
+    nd = np.zeros(count, dtype=np.uint32)
+    cap = 4 * count + 64
+    u = np.zeros(cap, dtype=np.float64)
+    done = C.c_size_t(0)
+    nu = lib.ref_zipf_trace(n, q, seed, count, vals, nd, u, cap, C.byref(done))
+    m = done.value
+    return vals[:m], nd[:m], u[:nu]
+

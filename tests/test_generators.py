@@ -1,9 +1,14 @@
 """Synthetic-input generators (include/ansx.h ansx_generate_host / _dev): the reference's distributions
 (src/generate_inputs.cpp:94-122, include/zipf_dist.hpp) as counter-based functions of (seed, index)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
 import ans_large_alphabet_amd as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_host_generators_follow_their_distributions():
@@ -27,6 +32,48 @@ def test_host_generators_follow_their_distributions():
         assert abs(got - w[:64]).max() < 1.5e-3, (lg, q)
         tail = (z > 1000).mean()
         assert abs(tail - w[1000:].sum()) < 2e-3, (lg, q)
+
+
+def _check_zipf_map(n, q, values, draws, u01):
+    """Every uniform the reference's rejection loop consumed must take the same turn here: rejected draws rejected,
+    the accepted one accepted with the reference's value."""
+    pos = 0
+    for v, d in zip(values, draws):
+        for j in range(d):
+            k, acc = A.zipf_from_uniform(n, q, u01[pos])
+            pos += 1
+            last = j == d - 1
+            assert acc == last, (n, q, v, j, d)
+            if last:
+                assert k == v, (n, q, v, k)
+    assert pos == len(u01)
+
+
+def test_zipf_map_equals_the_reference_class_on_its_own_uniforms():
+    """include/zipf_dist.hpp:49-59 (compiled into oracle/_ref, driven by std::mt19937 as generate_inputs.cpp does)
+    recorded the canonical uniforms of 10 500 values (tests/golden/zipf_trace.json, make_zipf_golden.py); the
+    package's map uniform -> (candidate, accept) must reproduce every one of its decisions and values.  (The
+    random STREAM is this build's own -- counter-based, so that a list can be drawn in shards on any number of GPUs;
+    the distribution code is pinned here.)"""
+    with open(os.path.join(GOLD, "zipf_trace.json")) as fh:
+        doc = json.load(fh)
+    total = 0
+    for c in doc["cases"]:
+        u = [float.fromhex(x) for x in c["u01"]]
+        _check_zipf_map(c["n"], c["q"], c["values"], c["draws"], u)
+        total += len(c["values"])
+    assert total >= 10000
+
+
+def test_zipf_map_equals_the_compiled_reference_live(oracle_built):
+    """The same comparison on fresh draws when oracle/_ref is present (authoring container and GPU box)."""
+    import oracle_lib as ol
+
+    if not ol.have_ref() or not hasattr(ol.ref(), "ref_zipf_trace"):
+        pytest.skip("oracle/_ref not built")
+    for n, q, seed in ((1 << 20, 1.2, 77), (1 << 24, 1.2, 78), (1 << 16, 1.0, 79)):
+        vals, nd, u = ol.ref_zipf_trace(n, q, seed, 20000)
+        _check_zipf_map(n, q, [int(x) for x in vals], [int(x) for x in nd], [float(x) for x in u])
 
 
 def test_generators_are_pure_functions_of_seed_and_index():

@@ -26,7 +26,7 @@ EXPORTS = [
     "ansx_container_info", "ansx_profile_enable", "ansx_profile_reset", "ansx_profile_get",
     "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div", "ansx_debug_set",
     "ansx_generate_dev", "ansx_generate_host", "ansx_last_encode_stats", "ansx_merge_containers_dev",
-    "ansx_zipf_from_uniform",
+    "ansx_zipf_from_uniform", "ansx_gather_containers",
 ]
 
 

@@ -4,6 +4,8 @@
 #include "../../include/ansx.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is resolved at first use (ansx_gather_containers)
 
 #include <algorithm>
 #include <cmath>
@@ -1296,6 +1298,34 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
 
 }  // namespace
 
+namespace {
+struct RcclApi {
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl_api()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+        a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+        a.ok = a.AllGather && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
 // ================================================================================= C ABI
 extern "C" {
 
@@ -1609,6 +1639,58 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
     HIPCHK(c, hipStreamSynchronize(s));  // hp is reused by the next call
     *out_bytes = (size_t)total;
     return ANSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU gather over RCCL: ncclAllGather of the container sizes, then one grouped
+// ncclSend / ncclRecv round -- every rank straight to the root, each over its own xGMI link -- and the merge
+// kernel on the root.  librccl is not a link-time dependency of this library: the five entry points are
+// resolved with dlopen at first use (a caller that holds an ncclComm_t has the library loaded already).
+int ansx_gather_containers(ansx_ctx* c, void* nccl_comm, int rank, int nranks, int root, const uint8_t* d_container,
+    size_t bytes, uint8_t* d_recv, size_t slot_bytes, uint8_t* d_merged, size_t merged_cap, size_t* merged_bytes,
+    void* stream)
+{
+    if (!c || !nccl_comm || !d_container || !merged_bytes || nranks < 1 || nranks > ANSX_MERGE_MAX_PARTS || rank < 0
+        || rank >= nranks || root < 0 || root >= nranks || bytes < sizeof(ansx_container_header))
+        return ANSX_ERR_ARG;
+    if (rank == root && (!d_recv || !d_merged || (slot_bytes & 15u) || ((uintptr_t)d_recv & 15u))) return ANSX_ERR_ARG;
+    const RcclApi& R = rccl_api();
+    if (!R.ok) return ANSX_ERR_NO_DEVICE;  // no RCCL library on this system
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    ncclComm_t comm = (ncclComm_t)nccl_comm;
+    *merged_bytes = 0;
+    // 1. sizes of all rank containers, everywhere (a rank that does not fit its slot fails the call on every rank)
+    int rc;
+    if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)ANSX_MERGE_MAX_PARTS + 2)))) return rc;
+    u64* d_sizes = (u64*)((u8*)c->misc.p + 64);
+    u64* h_sizes = (u64*)((u8*)c->h_pin + 64);
+    const u64 mine = (u64)bytes;
+    HIPCHK(c, hipMemcpyAsync(d_sizes + ANSX_MERGE_MAX_PARTS, &mine, 8, hipMemcpyHostToDevice, s));
+    if (R.AllGather(d_sizes + ANSX_MERGE_MAX_PARTS, d_sizes, 1, ncclUint64, comm, s) != ncclSuccess) return ANSX_ERR_HIP;
+    HIPCHK(c, hipMemcpyAsync(h_sizes, d_sizes, 8 * (size_t)nranks, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::vector<size_t> sizes((size_t)nranks);
+    for (int r = 0; r < nranks; r++) {
+        sizes[(size_t)r] = (size_t)h_sizes[r];
+        if (h_sizes[r] > slot_bytes || h_sizes[r] < sizeof(ansx_container_header)) return ANSX_ERR_CAPACITY;
+    }
+    // 2. every rank's container into its slot on the root
+    if (R.GroupStart() != ncclSuccess) return ANSX_ERR_HIP;
+    bool bad = false;
+    if (rank == root) {
+        for (int r = 0; r < nranks; r++)
+            if (r != root) bad |= R.Recv(d_recv + (size_t)r * slot_bytes, sizes[(size_t)r], ncclUint8, r, comm, s) != ncclSuccess;
+    } else {
+        bad |= R.Send(d_container, bytes, ncclUint8, root, comm, s) != ncclSuccess;
+    }
+    if (R.GroupEnd() != ncclSuccess || bad) return ANSX_ERR_HIP;
+    if (rank != root) return ANSX_OK;
+    HIPCHK(c, hipMemcpyAsync(d_recv + (size_t)root * slot_bytes, d_container, bytes, hipMemcpyDeviceToDevice, s));
+    // 3. one container
+    std::vector<const uint8_t*> parts((size_t)nranks);
+    for (int r = 0; r < nranks; r++) parts[(size_t)r] = d_recv + (size_t)r * slot_bytes;
+    return ansx_merge_containers_dev(c, parts.data(), sizes.data(), nranks, d_merged, merged_cap, merged_bytes, s);
 }
 
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out)

@@ -119,43 +119,54 @@ def cpu_baseline(sample, kind, f, block_ints=16384, budget_s=12.0):
     }
 
 
-def all_cores_baseline(sample, kind, f, block_ints, budget_s=10.0):
-    """The reference CPU path on every host core this process may use: blocks are independent encode() calls
-    (SURVEY 8d "optional all-cores row"), one Python thread per core, each calling into oracle/_ref (ctypes releases
-    the GIL).  Like-for-like with the GPU run: the same block size.  Bounded: stops handing out blocks when the
-    budget is spent."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from concurrent.futures import ThreadPoolExecutor
-
-    import numpy as np
-    import oracle_lib as ol
-
-    if not ol.have_ref():
-        return None
+def effective_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a
+    one-GPU job a share of the host's cores)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    parts = [np.ascontiguousarray(sample[a:a + block_ints]) for a in range(0, sample.size, block_ints)]
-    # size the sample to the budget from one timed block
-    t0 = time.perf_counter()
-    s0 = ol.ref_encode(kind, f, parts[0])
-    ol.ref_decode(kind, f, s0, parts[0].size)
-    per_block = max(time.perf_counter() - t0, 1e-6)
-    take = int(min(len(parts), max(cores, budget_s * cores / per_block / 2)))
-    parts = parts[:take]
-    n = sum(p_.size for p_ in parts)
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        t0 = time.perf_counter()
-        streams = list(ex.map(lambda p_: ol.ref_encode(kind, f, p_), parts))
-        t_enc = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        backs = list(ex.map(lambda sp: ol.ref_decode(kind, f, sp[0], sp[1].size), zip(streams, parts)))
-        t_dec = time.perf_counter() - t0
-    ok = all(np.array_equal(b_, p_) for b_, p_ in zip(backs, parts))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    cores = min(cores, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        cores = min(cores, max(1, q // int(fh2.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
+def all_cores_baseline(sample, kind, f, block_ints, budget_s=10.0):
+    """The reference CPU path on every host core this process may use: blocks are independent encode() calls
+    (SURVEY 8d "optional all-cores row"), native threads over oracle/_ref taking blocks from a shared counter
+    (oracle/ref_shim.cpp::ref_blocks_mt).  Like-for-like with the GPU run: the same block size.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+
+    if not ol.have_ref() or not hasattr(ol.ref(), "ref_blocks_mt"):
+        return None
+    cores = effective_cores()
+    # size the sample to the budget from a short single-thread probe
+    probe = np.ascontiguousarray(sample[:min(sample.size, 8 * block_ints)])
+    _, pe, pd, _ = ol.ref_blocks_mt(kind, f, probe, block_ints, 1)
+    per_int = max((pe + pd) / probe.size, 1e-12)
+    n = int(min(sample.size, max(block_ints, budget_s * cores / per_int)))
+    n -= n % block_ints if n > block_ints else 0
+    part = np.ascontiguousarray(sample[:n])
+    ok, t_enc, t_dec, tot = ol.ref_blocks_mt(kind, f, part, block_ints, cores)
     return {"value": n / (t_enc + t_dec) / 1e6, "unit": "Mints/s", "cores": cores, "kind": "reference", "block_ints": block_ints,
-            "ints": n, "enc_mints": n / t_enc / 1e6, "dec_mints": n / t_dec / 1e6, "roundtrip_ok": ok,
-            "sample": "first %d ints of the workload in %d blocks, one Python thread per core over oracle/_ref" % (n, len(parts))}
+            "ints": n, "enc_mints": n / t_enc / 1e6, "dec_mints": n / t_dec / 1e6, "bits_per_int": 8.0 * tot / n, "roundtrip_ok": bool(ok),
+            "cpu": _cpu_model(),
+            "sample": "first %d ints of the workload in blocks of %d, %d native threads over oracle/_ref" % (n, block_ints, cores)}
 
 
 def gpu_enc_dec_rates(torch, codec, d_in, n, d_out, cap, d_back, stream, runs=5):

@@ -157,6 +157,18 @@ int ansx_decode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* d_in, 
 int ansx_merge_containers_dev(ansx_ctx* ctx, const uint8_t* const* d_parts, const size_t* part_bytes, int nparts,
     uint8_t* d_out, size_t out_capacity, size_t* out_bytes, void* stream);
 
+/* The same over RCCL, for a C / C++ host with one process (or thread) per GPU: every rank calls this
+ * with its own container; sizes are exchanged with ncclAllGather, every rank sends its container straight to the root
+ * (grouped ncclSend / ncclRecv: one hop, each sender on its own xGMI link), and the root merges the slots with
+ * ansx_merge_containers_dev.  nccl_comm: an ncclComm_t of the system's RCCL (librccl.so.1 is resolved at first use,
+ * this library does not link it).  d_recv (root only): nranks * slot_bytes bytes, 16-byte aligned slots; a rank
+ * container larger than slot_bytes fails the call on every rank (ANSX_ERR_CAPACITY).  *merged_bytes: size of the
+ * merged container on the root, 0 elsewhere.  Blocks until the sizes are known; the transfers and the merge run on
+ * `stream`. */
+int ansx_gather_containers(ansx_ctx* ctx, void* nccl_comm, int rank, int nranks, int root, const uint8_t* d_container,
+    size_t bytes, uint8_t* d_recv, size_t slot_bytes, uint8_t* d_merged, size_t merged_cap, size_t* merged_bytes,
+    void* stream);
+
 /* Parse + validate a container header held in HOST memory. */
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out);
 

@@ -21,7 +21,10 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ans_byte.hpp"
@@ -212,6 +215,49 @@ size_t ref_zipf_trace(uint32_t n, double q, uint32_t seed, size_t count, uint32_
     }
     *n_values = i;
     return nu;
+}
+
+
+// All-cores CPU row for bench.py (SURVEY 8d "optional all-cores row"): blocks are independent encode() calls, so
+// `threads` std::threads take blocks of block_ints ints from a shared counter -- first every block is encoded
+// (timed), then every block decoded (timed) and compared.  Returns 0 when every block round-trips.
+int ref_blocks_mt(int kind, int f, const uint32_t* in, size_t n, size_t block_ints, int threads, double* enc_seconds,
+    double* dec_seconds, size_t* total_bytes)
+{
+    const size_t nb = (n + block_ints - 1) / block_ints;
+    std::vector<std::vector<uint8_t>> streams(nb);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto run = [&](bool enc) {
+        next = 0;
+        std::vector<std::thread> th;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; t++)
+            th.emplace_back([&, enc] {
+                std::vector<uint32_t> back;
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= nb) break;
+                    const size_t lo = b * block_ints, cnt = std::min(block_ints, n - lo);
+                    if (enc) {
+                        streams[b].resize(cnt * 8 + 65536 + 4 * 16400);
+                        streams[b].resize(ref_encode(kind, f, in + lo, cnt, streams[b].data(), streams[b].size()));
+                    } else {
+                        back.resize(cnt);
+                        ref_decode(kind, f, streams[b].data(), streams[b].size(), back.data(), cnt);
+                        if (memcmp(back.data(), in + lo, cnt * 4) != 0) bad = 1;
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    *enc_seconds = run(true);
+    *dec_seconds = run(false);
+    size_t tot = 0;
+    for (const auto& s : streams) tot += s.size();
+    *total_bytes = tot;
+    return bad.load();
 }
 
 } // extern "C"

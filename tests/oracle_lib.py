@@ -96,6 +96,10 @@ def _load_ref(name="libans_ref.so"):
     lib.ref_serialize_prelude.argtypes = [_u32p, C.c_size_t, C.c_uint64, _u8p]
     lib.ref_load_prelude.restype = C.c_size_t
     lib.ref_load_prelude.argtypes = [_u8p, _u32p]
+    if hasattr(lib, "ref_blocks_mt"):
+        lib.ref_blocks_mt.restype = C.c_int
+        lib.ref_blocks_mt.argtypes = [C.c_int, C.c_int, _u32p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_size_t)]
     if hasattr(lib, "ref_zipf_trace"):
         lib.ref_zipf_trace.restype = C.c_size_t
         lib.ref_zipf_trace.argtypes = [C.c_uint32, C.c_double, C.c_uint32, C.c_size_t, _u32p, _u32p,
@@ -325,4 +329,14 @@ def ref_zipf_trace(n, q, seed, count):
     nu = lib.ref_zipf_trace(n, q, seed, count, vals, nd, u, cap, C.byref(done))
     m = done.value
     return vals[:m], nd[:m], u[:nu]
+
+
+def ref_blocks_mt(kind, f, data, block_ints, threads):
+    """Every block of `data` encoded, then decoded, by `threads` native threads over the compiled reference:
+    (ok, encode seconds, decode seconds, total stream bytes)."""
+    lib = ref()
+    e, d, tot = C.c_double(0), C.c_double(0), C.c_size_t(0)
+    bad = lib.ref_blocks_mt(kind, f, np.ascontiguousarray(data, dtype=np.uint32), data.size, block_ints, threads,
+                            C.byref(e), C.byref(d), C.byref(tot))
+    return bad == 0, e.value, d.value, tot.value
 

@@ -487,6 +487,23 @@ def test_native_merge_equals_whole_encode(A, ctx, kind, f, block, ckpt, world):
             ctx.merge_containers_dev(ptrs[::-1], sizes[::-1], out.data_ptr(), out.numel())
 
 
+def test_rccl_gather_entry_point_from_cpp(tmp_path):
+    """ansx_gather_containers (ncclAllGather of sizes + grouped ncclSend/ncclRecv + merge on the root) driven from
+    C++ with one thread per visible GPU: tests/tools/gather_selftest.cpp.  On a one-GPU box this is a one-rank
+    communicator (size exchange, local slot copy, merge, decode of the merged container); on a node it is the whole
+    path over xGMI."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = str(tmp_path / "gather_selftest")
+    cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+           os.path.join(here, "tools", "gather_selftest.cpp"), "-o", exe, "-L" + os.path.join(root, "ans_large_alphabet_amd"), "-lansx",
+           "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread", "-Wl,-rpath," + os.path.join(root, "ans_large_alphabet_amd"),
+           "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gather_selftest OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_native_merge_of_compacted_containers_and_bad_parts(A, ctx):
     """Containers with per-block alphabet compaction (kind word | 0x100: ANSint, ANSfold + compact) merge like the
     others; a part whose header does not describe its own layout (block count, payload offset) is refused

@@ -165,12 +165,14 @@ class ANSmsb(_Codec):
 
 
 class ANSint(_Codec):
-    """methods.hpp:484-497 (include/ans_int.hpp), name() == "ANS": always with per-block alphabet compaction."""
+    """methods.hpp:484-497 (include/ans_int.hpp), name() == "ANS".  compact=True (default): per-block alphabet
+    compaction, any values.  compact=False: the values themselves are the symbols and must be below 16384;
+    block_ints=SINGLE_STREAM then gives exactly the bytes of ANSint::encode (ans_int_compress)."""
     KIND = L.INT
     PREFIX = "ANS"
 
-    def __init__(self, ctx=None, block_ints=0, ckpt_interval=0):
-        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval, compact=True)
+    def __init__(self, ctx=None, block_ints=0, ckpt_interval=0, compact=True):
+        super().__init__(0, ctx=ctx, block_ints=block_ints, ckpt_interval=ckpt_interval, compact=compact)
 
 
 # ---------------------------------------------------------------- container parsing (host)

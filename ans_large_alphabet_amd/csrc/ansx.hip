@@ -179,9 +179,9 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     const u32 flags = opts ? opts->flags : 0;
     if (flags & ~(u32)ANSX_FLAG_COMPACT_ALPHABET) return ANSX_ERR_ARG;
     const bool pa = (flags & ANSX_FLAG_COMPACT_ALPHABET) != 0;
-    // ANSint models every value up to the largest (ans_int.hpp:40-48): only meaningful per block on the
-    // dense ranks of the compaction layer; ANSrfold brings its own remap
-    if (kind == ANSX_INT && !pa) return ANSX_ERR_ARG;
+    // ANSint models every value up to the largest (ans_int.hpp:40-48).  Without the compaction layer the values
+    // themselves must fit the 16384-symbol model (ANSX_ERR_DOMAIN otherwise: checked on the device); with it the
+    // codec runs on a block's dense ranks.  ANSrfold brings its own remap.
     if (kind == ANSX_RFOLD && pa) return ANSX_ERR_ARG;
     if (pa) {
         if (bi == ANSX_SINGLE_STREAM) return ANSX_ERR_ARG;
@@ -334,8 +334,9 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     if ((rc = ensure(c, c->hist, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->sortF, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->sortSym, (size_t)NB * NSP * 2))) return rc;
-    if ((rc = ensure(c, c->attS, (size_t)NB * ANSX_ATTEMPTS * NSP * 2))) return rc;
-    if ((rc = ensure(c, c->prevS, (size_t)NB * NSP * 2))) return rc;
+    const size_t fbytes = g.kind == ANSX_INT ? 4 : 2;  // candidate frequencies: u32 for ANSint (ans_int.hpp:30-34), u16 otherwise
+    if ((rc = ensure(c, c->attS, (size_t)NB * ANSX_ATTEMPTS * NSP * fbytes))) return rc;
+    if ((rc = ensure(c, c->prevS, (size_t)NB * NSP * fbytes))) return rc;
     if ((rc = ensure(c, c->attMeta, (size_t)NB * ANSX_ATTEMPTS * 16))) return rc;
     if (!c->log2lut.p) {  // stage-1 table of the portable log2, once per context (1.5 MB)
         if ((rc = ensure(c, c->log2lut, (size_t)65536 * sizeof(ansx_log2_ent)))) return rc;
@@ -440,7 +441,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         hterm = (double*)c->hterm.p;
     }
     LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, h_in_hist ? (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (size_t)NSP * 8 + 80 : (size_t)NSP * 4, s, src, g, chunk, cpb,
-        NSP, hist, hterm, (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, 1u << 30);
+        NSP, hist, hterm, (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)

@@ -117,11 +117,15 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     u32* const my_hist = lds_hist + (tid & 3) * cstride;
     __syncthreads();
     const ansx_map mp = g.map;
+    const bool ident = g.kind == 3;  // ANSint (wave-uniform)
     u32 lmax = 0, bad = 0;
     auto take = [&](u32 x) {
         bad |= (x >= value_limit) ? 1u : 0u;
         u32 k = map_nbytes(mp, x);
         u32 s = map_sym(mp, x, k);
+        // (fold / msb maps keep every 32-bit value inside the symbol array; ANSint's identity map does not: a value
+        // at or above value_limit = NSP is a domain error, counted as symbol 0 so that nothing is written out of range)
+        if (ident) s = s < NSP ? s : 0u;
         atomicAdd(&my_hist[s], 1u);
         lmax = s > lmax ? s : lmax;
     };
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
     // write / read 16 contiguous bytes per symbol (scattered 2-byte stores into per-attempt rows
     // cost 12x write amplification, measured with WRITE_SIZE)
     u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + t;
+    const bool wide = g.kind == 3;  // candidate frequencies as u32 (the buffer is sized for it)
     u32 maxS = 0;
     const u32 sigma = B.sigma;
     bool stop = dead;
@@ -585,7 +590,8 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
         v = 0.5 + v;
         u32 sc = (u32)v;
         if (sc == 0) sc = 1;
-        S[sy * ANSX_ATTEMPTS] = (u16)(sc > 65535u ? 65535u : sc);
+        if (wide) ((u32*)attS)[((u64)b * NSP + sy) * ANSX_ATTEMPTS + t] = sc;  // ANSint: 32-bit frequencies (ans_int.hpp:30-34)
+        else S[sy * ANSX_ATTEMPTS] = (u16)(sc > 65535u ? 65535u : sc);
         maxS = sc > maxS ? sc : maxS;
         Md = Md - (double)sc;
         fsd = fsd - frd;
@@ -678,7 +684,8 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
         const u32 h8[8] = { ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w };
         u32 s8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) s8[u] = S[(u64)(i0 + u) * ANSX_ATTEMPTS];  // rows are NSP >= ns+8 long
+        for (int u = 0; u < 8; u++)  // rows are NSP >= ns+8 long
+            s8[u] = wide ? ((const u32*)attS)[((u64)b * NSP + i0 + u) * ANSX_ATTEMPTS + t] : (u32)S[(u64)(i0 + u) * ANSX_ATTEMPTS];
         if (i0 + 8 < ns) {
             ha = *(const uint4*)(h + i0 + 8);
             hb = *(const uint4*)(h + i0 + 12);
@@ -689,12 +696,14 @@ __global__ __launch_bounds__(256) void k_scale_attempts(ansx_geo g, u32 NSP, u32
         // value is bit-identical to evaluating the function on q), the exponent part is e(S) - sh
         ansx_log2_ent le[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) le[u] = l2lut[s8[u]];
+        for (int u = 0; u < 8; u++) le[u] = l2lut[s8[u] < 65536u ? s8[u] : 0u];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const bool valid = (i0 + u < ns) && (h8[u] != 0);
             const double p = !valid ? 0.0 : n_pow2 ? (double)h8[u] * inv_nd : ansx_div_int31((double)h8[u], nd);
-            const double lg = ansx_log2_stage2(ansx_log2_e_of_int(s8[u]) - (int)sh, le[u].y, le[u].ylo);
+            double lg = ansx_log2_stage2(ansx_log2_e_of_int(s8[u]) - (int)sh, le[u].y, le[u].ylo);
+            // (ANSint frequencies above the table: the function itself; q = S * 2^-sh is exact)
+            if (s8[u] >= 65536u) lg = ansx_log2_portable((double)s8[u] * ansx_bits_to_f64((u64)(1023 - (int)sh) << 52));
             tm[u] = p * (valid ? lg : 0.0);  // absent: p * log2(1) = +0.0
         }
 #pragma unroll
@@ -722,6 +731,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
     if (B->resolved) return;
+    const bool wide = g.kind == 3;  // ANSint: candidate frequencies are u32 (k_scale_attempts)
     const u32 ns = B->max_sym + 1;
     const u32* h = hist + (u64)b * NSP;
     const double thr = B->thr;
@@ -762,9 +772,16 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     if (chosen == -2) {
         // still undecided after this batch: remember the last rejected success
         if (prev >= (int)(batch * ANSX_ATTEMPTS)) {
-            const u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + (prev - batch * ANSX_ATTEMPTS);
-            u16* P = prevS + (u64)b * NSP;
-            for (u32 s = lane; s < ns; s += 64) P[s] = S[(u64)s * ANSX_ATTEMPTS];
+            const u32 pt = (u32)prev - batch * ANSX_ATTEMPTS;
+            if (wide) {
+                const u32* S = (const u32*)attS + (u64)b * ANSX_ATTEMPTS * NSP + pt;
+                u32* P = (u32*)prevS + (u64)b * NSP;
+                for (u32 s = lane; s < ns; s += 64) P[s] = S[(u64)s * ANSX_ATTEMPTS];
+            } else {
+                const u16* S = attS + (u64)b * ANSX_ATTEMPTS * NSP + pt;
+                u16* P = prevS + (u64)b * NSP;
+                for (u32 s = lane; s < ns; s += 64) P[s] = S[(u64)s * ANSX_ATTEMPTS];
+            }
         }
         if (lane == 0) {
             B->prev = prev;
@@ -777,10 +794,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         }
         return;
     }
-    // ANSint frames above 2^16 (32-bit frequencies, ans_int.hpp:100-110) are not supported by this build's
-    // encoder / decoder tables: refused rather than mis-coded.  (None occurred in 3000 adversarial
-    // low-entropy blocks of up to 16384 ints; the reference caps the other codecs at 2^16 itself.)
-    if (chosen >= 0 && g.kind == 3 && B->m0_log2 + (u32)chosen > 16) chosen = -1;
+    // (ANSint frames may exceed 2^16 -- 32-bit frequencies, ans_int.hpp:30-34,50: the 16-byte table entries, the
+    // integer-state encoder and the slot -> symbol decoder take any frame the reference's own arithmetic survives;
+    // beyond 2^27 its 64-bit renormalisation bound K * RADIX * freq overflows, so that is where this build stops)
+    if (chosen >= 0 && g.kind == 3 && B->m0_log2 + (u32)chosen > 27) chosen = -1;
     if (chosen < 0) {  // "prev" is the all-zero vector: reference's degenerate exit
         if (lane == 0) {
             B->resolved = 1;
@@ -793,7 +810,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     const bool from_batch = chosen >= (int)(batch * ANSX_ATTEMPTS);
     const u16* S = from_batch ? attS + (u64)b * ANSX_ATTEMPTS * NSP + (chosen - batch * ANSX_ATTEMPTS)
                               : prevS + (u64)b * NSP;
+    const u32* S32 = from_batch ? (const u32*)attS + (u64)b * ANSX_ATTEMPTS * NSP + (chosen - batch * ANSX_ATTEMPTS)
+                                : (const u32*)prevS + (u64)b * NSP;
     const u32 sstride = from_batch ? ANSX_ATTEMPTS : 1u;
+    auto chosen_freq = [&](u32 s) -> u32 { return wide ? S32[(u64)s * sstride] : (u32)S[(u64)s * sstride]; };
     // exclusive scan of the chosen frequencies -> encoder table (ans_fold.hpp:82-91):
     // lane = symbol, 64 symbols per pass (coalesced), wave prefix sum, carry between passes
     ansx_enc_entry* tab = table + (u64)b * NSP;
@@ -813,7 +833,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
         for (u32 r = 0; r < SEL_PRE; r++) {
             const u32 s = r * 64 + lane;
             hpre[r] = s < ns ? h[s] : 0u;
-            spre[r] = s < ns ? (u32)S[(u64)s * sstride] : 0u;
+            spre[r] = s < ns ? chosen_freq(s) : 0u;
         }
     }
     for (u32 s0 = 0, r = 0; s0 < ns; s0 += 64, r++) {
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
                 }
         } else {
             hv = s < ns ? h[s] : 0u;
-            sv = s < ns ? (u32)S[(u64)s * sstride] : 0u;
+            sv = s < ns ? chosen_freq(s) : 0u;
         }
         const u32 fr = hv ? sv : 0u;
         u32 incl = fr;
@@ -1200,22 +1220,28 @@ __device__ __forceinline__ void enc_update(enc_lane& L, u32 x, const enc_ent e, 
     const u32 eb = x & ((1u << (8 * k)) - 1u);
     u64 st = L.st;
     // renormalise: state >= K*RADIX*freq  <=>  (state >> 36) >= freq   (ans_fold.hpp:105-110)
-    const bool rn = active && ((u32)(st >> 36) >= freq);
+    const bool rn = active && ((st >> 36) >= (u64)freq);
     const u32 w = (u32)st;
     if (rn) st >>= 32;
     // exact q = st / freq, r = st % freq; st < 2^36 * freq <= 2^52 (ans_fold.hpp:111).
     // rcp is 1/freq to < 2^-40 relative, so trunc(st * rcp) is within +-1 of the quotient;
     // the remainder of the estimate lies in (-2^16, 2^17), so 32-bit arithmetic decides it.
-    const u32 st_hi = (u32)(st >> 32), st_lo = (u32)st;
-    const double std_ = __builtin_fma((double)st_hi, 4294967296.0, (double)st_lo);
-    const double qd = std_ * e.rcp;                             // < 2^36 + 1
-    const u32 q_hi = (u32)(qd * (1.0 / 4294967296.0));          // trunc
-    const u32 q_lo = (u32)__builtin_fma(-(double)q_hi, 4294967296.0, qd);
-    int r = (int)(st_lo - q_lo * freq);
-    const int adj = (r < 0) ? -1 : ((r >= (int)freq) ? 1 : 0);
-    r -= adj * (int)freq;
-    const u64 q = (((u64)q_hi << 32) | q_lo) + (u64)(i64)adj;
-    st = (q << logM) + (u64)((u32)r + e.base);
+    if (logM > 16) {
+        // frames above 2^16 (ANSint, whole-list modes): the state no longer fits a double -- plain 64-bit division
+        const u64 q = st / freq, r = st % freq;
+        st = (q << logM) + r + e.base;
+    } else {
+        const u32 st_hi = (u32)(st >> 32), st_lo = (u32)st;
+        const double std_ = __builtin_fma((double)st_hi, 4294967296.0, (double)st_lo);
+        const double qd = std_ * e.rcp;                             // < 2^36 + 1
+        const u32 q_hi = (u32)(qd * (1.0 / 4294967296.0));          // trunc
+        const u32 q_lo = (u32)__builtin_fma(-(double)q_hi, 4294967296.0, qd);
+        int r = (int)(st_lo - q_lo * freq);
+        const int adj = (r < 0) ? -1 : ((r >= (int)freq) ? 1 : 0);
+        r -= adj * (int)freq;
+        const u64 q = (((u64)q_hi << 32) | q_lo) + (u64)(i64)adj;
+        st = (q << logM) + (u64)((u32)r + e.base);
+    }
     if (active) L.st = st;
     const u32 c = active ? (k + (rn ? 4u : 0u)) : 0u;
     u32 total;
@@ -2733,6 +2759,7 @@ __device__ __forceinline__ u32 dec_make_pv(const ansx_map& f, u32 sym, bool rf, 
     return (k << 30) | (v0 & ANSX_PV_MASK);
 }
 struct dec_lut_table {
+    static constexpr bool WIDE = true;  // any frame size: 32-bit frequencies, full 64-bit state arithmetic
     const u32* cum;
     const u16* s2s;
     ansx_map f;
@@ -2748,6 +2775,7 @@ struct dec_lut_table {
     }
 };
 struct dec_lut_rank {
+    static constexpr bool WIDE = false;
     const uint2* bwp;  // {bitmap word, (set bits before it) - 1 + (LDS byte address of ep) / 8}
     const uint2* ep;   // per present symbol: {base << 16 | freq, k << 30 | value without its exception bytes}
     // the second word of a bitmap entry, see above (ep is 8-byte aligned)
@@ -2789,8 +2817,13 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     // ans_fold.hpp:218-220: fr * (st >> logM) + (slot - base).  st < 2^52 for frames up to 2^16, so
     // the high word of the quotient is small: one 32x32->64 mad, and a 24-bit mad into its high word
     const u64 qs = st >> logM;
-    const u64 t = (u64)fr * (u32)qs + (u64)(slot - base);
-    u64 ns_ = ((u64)((u32)(t >> 32) + __umul24(fr, (u32)(qs >> 32))) << 32) | (u32)t;
+    u64 ns_;
+    if constexpr (LUT::WIDE) {
+        ns_ = (u64)fr * qs + (u64)(slot - base);  // frames above 2^16: freq up to 2^27, quotient below 2^36
+    } else {
+        const u64 t = (u64)fr * (u32)qs + (u64)(slot - base);
+        ns_ = ((u64)((u32)(t >> 32) + __umul24(fr, (u32)(qs >> 32))) << 32) | (u32)t;
+    }
     const bool rn = active && (ns_ < Lb);
     const u32 k = pv >> 30;
     const u32 cq = active ? ((k << qc.ql8) + (rn ? qc.four_pos : 0u)) : 0u;

@@ -54,9 +54,11 @@ typedef enum {
     ANSX_FOLD = 0,  /* ANSfold<f>  */
     ANSX_RFOLD = 1, /* ANSrfold<f> */
     ANSX_MSB = 2,   /* ANSmsb (include/methods.hpp:499-515 -> include/ans_msb.hpp); fidelity must be 0 */
-    ANSX_INT = 3    /* ANSint, name() == "ANS" (include/methods.hpp:484-497 -> include/ans_int.hpp); fidelity must be 0;
-                       only with ANSX_FLAG_COMPACT_ALPHABET (its model spans every value up to the largest, which
-                       is only workable per block on dense ranks); frames are limited to 2^16 (ANSX_ERR_MODEL) */
+    ANSX_INT = 3    /* ANSint, name() == "ANS" (include/methods.hpp:484-497 -> include/ans_int.hpp); fidelity must be 0.
+                       Its model spans every value up to the largest: plain, the values must be below 16384
+                       (ANSX_ERR_DOMAIN), block container or ANSX_SINGLE_STREAM (= the bytes of ans_int_compress);
+                       with ANSX_FLAG_COMPACT_ALPHABET any values, coded as a block's dense ranks.  32-bit
+                       frequencies: frames up to 2^27 (beyond, the reference's own 64-bit bound overflows) */
 } ansx_kind;
 
 typedef enum {

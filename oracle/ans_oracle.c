@@ -438,8 +438,9 @@ static int cmp_cv(const void* a, const void* b) /* (-count, value) ascending: an
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n)
 {
     /* ANSint: the model spans every value up to the largest; this oracle covers inputs whose largest value
-     * does not exceed n + 1024 (the per-block dense remap of pseudo_adaptive.cpp, small-valued lists) */
-    if (kind == ANS_ORACLE_INT) return 16 + 8 * (n + 1027) + 4 * n + 32 + 64;
+     * is below 16384 (the alphabet the GPU path takes: lists of small values, ans_int.hpp:40-48) or does not exceed
+     * n + 1024 (the per-block dense remap of pseudo_adaptive.cpp) */
+    if (kind == ANS_ORACLE_INT) return 16 + 8 * ((n > 16384 ? n : 16384) + 1027) + 4 * n + 32 + 64;
     size_t nsyms_max = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (size_t)fold_T(f) + 3u * (size_t)fold_D(f);
     size_t hdr = kind == ANS_ORACLE_RFOLD ? 4 + 4 * (size_t)fold_T(f) : 0;
     return hdr + 8 + 4 * nsyms_max + 8 + 7 * n + 32;
@@ -456,7 +457,7 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     if (kind == ANS_ORACLE_INT) {
         for (size_t i = 0; i < n; i++)
             if (in[i] > int_max) int_max = in[i];
-        if ((size_t)int_max > n + 1024) return 0; /* outside this oracle's range, see ans_oracle_bound */
+        if ((size_t)int_max > n + 1024 && int_max >= 16384) return 0; /* outside this oracle's range, see ans_oracle_bound */
     }
     const uint32_t T = kind == ANS_ORACLE_INT ? 0xFFFFFFFFu : fold_T(f); /* ANSint never strips bytes */
     const uint32_t MAX_SIGMA = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (kind == ANS_ORACLE_INT ? int_max + 1 : fold_max_sigma(f));
@@ -687,7 +688,7 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     }
     uint32_t max_sym_peek; /* guard against corrupt input: the alphabet has < 2^(f+9) symbols */
     vbyte_get(p, &max_sym_peek);
-    if (kind == ANS_ORACLE_INT ? (size_t)max_sym_peek > n + 1024
+    if (kind == ANS_ORACLE_INT ? ((size_t)max_sym_peek > n + 1024 && max_sym_peek >= 16384)
                                : max_sym_peek >= (kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f)))
         return -2;
     uint32_t* nfreqs = (uint32_t*)calloc((size_t)max_sym_peek + 2, sizeof(uint32_t));

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 enum { ANS_ORACLE_FOLD = 0, ANS_ORACLE_RFOLD = 1, ANS_ORACLE_MSB_KIND = 2 /* ANSmsb, include/ans_msb.hpp; f ignored */,
-    ANS_ORACLE_INT_KIND = 3 /* ANSint, include/ans_int.hpp (methods.hpp:484-497); f ignored; inputs with max value <= n + 1024 */ };
+    ANS_ORACLE_INT_KIND = 3 /* ANSint, include/ans_int.hpp (methods.hpp:484-497); f ignored; inputs with max value < 16384 or <= n + 1024 */ };
 
 typedef struct {
     uint32_t max_sym;       /* largest folded symbol in the block                         */

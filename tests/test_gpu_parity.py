@@ -67,7 +67,6 @@ def codec_for(A, ctx, kind, f, **kw):
     if kind == ol.MSB:
         return A.ANSmsb(ctx=ctx, **kw)
     if kind == ol.INT:
-        kw.pop("compact", None)
         return A.ANSint(ctx=ctx, **kw)
     cls = A.ANSfold if kind == ol.FOLD else A.ANSrfold
     return cls(f, ctx=ctx, **kw)
@@ -1110,6 +1109,50 @@ def test_compaction_argument_and_domain_errors(A, ctx):
     bad[A.parse_container(cont)["header"].payload_offset] ^= 0x5A    # alphabet size of block 0
     with pytest.raises(A.AnsxError):
         codec.decode(bad, small.size)
+
+
+def _ansint_golden_input(e):
+    if e["input"] == "family":
+        return np.minimum(ol.gen_inputs(e["family"], e["n"], e["seed"]), np.uint32(e["clip"]))
+    d = np.zeros(e["n"], dtype=np.uint32)
+    for pos, val in e["pairs"]:
+        d[pos] = val
+    return d
+
+
+def test_plain_ansint_is_a_drop_in(A, ctx):
+    """ANSint without the compaction layer (methods.hpp:484-497): in single-stream mode the GPU writes exactly the bytes
+    of ans_int_compress -- tests/golden/ansint.json, made by the real reference, frames 2^5 .. 2^20 (32-bit frequencies,
+    the 64-bit-division encoder step and the wide decoder arithmetic above 2^16) -- decodes reference-made streams, and
+    its block container holds the oracle's stream of every block."""
+    with open(os.path.join(GOLD, "ansint.json")) as fh:
+        gold = json.load(fh)
+    wide = 0
+    for e in gold:
+        d = _ansint_golden_input(e)
+        tag = (e.get("family", "sparse"), e["n"], e["log2_frame"])
+        codec = A.ANSint(ctx=ctx, block_ints=A.SINGLE_STREAM, compact=False)
+        stream = codec.encode(d)
+        assert stream.size == e["stream_len"], tag
+        if "stream_hex" in e:
+            assert stream.tobytes().hex() == e["stream_hex"], tag
+            assert np.array_equal(codec.decode(np.frombuffer(bytes.fromhex(e["stream_hex"]), dtype=np.uint8), d.size), d), tag
+        else:
+            assert hashlib.sha256(stream.tobytes()).hexdigest() == e["stream_sha256"], tag
+        assert np.array_equal(codec.decode(stream, d.size), d), tag
+        wide += e["log2_frame"] > 16
+    assert wide >= 2
+    # block container: every block stream is the oracle's (and the reference's) ANSint stream of that block
+    for fam, n in (("zipf20s1.2", 70001), ("uniform12", 40000), ("geom0.01", 33000)):
+        d = np.minimum(ol.gen_inputs(fam, n, seed=7), np.uint32(16383))
+        codec = A.ANSint(ctx=ctx, block_ints=16384, ckpt_interval=1024, compact=False)
+        cont = codec.encode(d)
+        check_container(A, cont, d, ol.INT, 0, 16384, 1024)
+        assert np.array_equal(codec.decode(cont, n), d)
+    # values the 16384-symbol model cannot hold: refused, not mis-coded
+    with pytest.raises(A.AnsxError) as ei:
+        A.ANSint(ctx=ctx, compact=False).encode(np.array([1, 2, 16384, 3] * 100, dtype=np.uint32))
+    assert ei.value.status == 6  # ANSX_ERR_DOMAIN
 
 
 def test_golden_compaction_fixtures(A, ctx):

@@ -344,3 +344,32 @@ def test_golden_compaction_and_ansint():
             s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
             assert len(s) == e["stream_len"], tag
             assert hashlib.sha256(ol.canonicalize(s, info).tobytes()).hexdigest() == e["stream_sha256"], tag
+
+
+def _ansint_golden_input(e):
+    if e["input"] == "family":
+        return np.minimum(ol.gen_inputs(e["family"], e["n"], e["seed"]), np.uint32(e["clip"]))
+    d = np.zeros(e["n"], dtype=np.uint32)
+    for pos, val in e["pairs"]:
+        d[pos] = val
+    return d
+
+
+def test_golden_plain_ansint_streams(oracle_built):
+    """tests/golden/ansint.json: ans_int_compress bytes made by the real reference (make_ansint_golden.py) on lists whose
+    values fit the GPU path's 16384-symbol model, frames from 2^5 to 2^20 (32-bit frequencies above 2^16)."""
+    with open(os.path.join(GOLD, "ansint.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold) >= 28 and max(e["log2_frame"] for e in gold) > 16
+    for e in gold:
+        d = _ansint_golden_input(e)
+        assert hashlib.sha256(d.tobytes()).hexdigest() == e["input_sha256"]
+        s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+        c = ol.canonicalize(s, info)
+        assert c.size == e["stream_len"] and info.log2_frame == e["log2_frame"]
+        if "stream_hex" in e:
+            assert c.tobytes().hex() == e["stream_hex"]
+        else:
+            assert hashlib.sha256(c.tobytes()).hexdigest() == e["stream_sha256"]
+        assert np.array_equal(ol.oracle_decode(ol.INT, 0, s, d.size), d)
+

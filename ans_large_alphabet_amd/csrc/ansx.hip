@@ -291,8 +291,20 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
             const size_t lds = 6 * (size_t)opt_slots + sel_bytes;
             HIPCHK(c, hipFuncSetAttribute((const void*)k_rfold_remap_hash2,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef ANSX_STAMPS_RF
+            { static unsigned long long z[3] = { 0, 0, 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, 24, 4101 * 8); }
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, s);
+#endif
             LAUNCH(c, "k_rfold_remap", k_rfold_remap_hash2, g.nblocks, 1024, lds, s, d_in, g, opt_slots, mapped,
                 mostfreq, blk, gflags);
+#ifdef ANSX_STAMPS_RF
+            {
+                (void)hipEventRecord(e1, s); (void)hipStreamSynchronize(s);
+                float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+                unsigned long long z[3]; (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), 24, 4101 * 8);
+                fprintf(stderr, "[stamps] k_rfold_remap_hash2: events %.3f ms; workgroup lifetimes: max %llu ticks, mean %.0f ticks, %llu above 40 us\n", ms, z[0], (double)z[1] / g.nblocks, z[2]);
+            }
+#endif
             return ANSX_OK;
         }
         const size_t lds = 6 * (size_t)ANSX_RF_SLOTS + sel_bytes;
@@ -1053,7 +1065,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
     const size_t LDS_LIMIT = 150 * 1024;
     // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
-    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16);
+    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16) + ANSX_DEC_SCRATCH;
     if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !c->dbg.decode_table) {
         // per-quad stream rings when every segment of a full block has the same length; the (at
         // most one) partial block of the container then reads its stream straight from HBM
@@ -1370,18 +1382,32 @@ int ansx_last_encode_stats(const ansx_ctx* c, ansx_encode_stats* out)
     *out = c->last;
 #ifdef ANSX_STAMPS
     {
-        static unsigned long long h[16 * 256];
+        static unsigned long long h[16 * 256 + 16];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)) == hipSuccess) {
             double acc[16] = {};
             int nn = 0;
+#ifdef ANSX_STAMPS_RF
+            const int last = 8;
+#else
+            const int last = 10;
+#endif
             for (int w = 0; w < 256; w++) {
-                if (!h[w * 16] || !h[w * 16 + 10]) continue;
+                if (!h[w * 16] || !h[w * 16 + last]) continue;
                 nn++;
-                for (int i = 1; i <= 10; i++) acc[i] += (double)(h[w * 16 + i] - h[w * 16 + i - 1]);
+                for (int i = 1; i <= last; i++) acc[i] += (double)(h[w * 16 + i] - h[w * 16 + i - 1]);
             }
             fprintf(stderr, "[stamps] %d workgroups, 100 MHz ticks per phase:", nn);
             for (int i = 1; i <= 10; i++) fprintf(stderr, " %d:%.0f", i, nn ? acc[i] / nn : 0.0);
             fprintf(stderr, "\n");
+#ifdef ANSX_STAMPS_RF
+            {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (int w = 0; w < 256; w++) if (h[w * 16] && h[w * 16 + 8]) { t0 = std::min(t0, h[w * 16]); t1 = std::max(t1, h[w * 16 + 8]); }
+                fprintf(stderr, "[stamps] rfold: first start .. last end = %llu ticks\n", t1 - t0);
+                for (int w = 0; w < 256; w += 8)
+                    fprintf(stderr, "[stamps]  wg %5d start %7llu dur %5llu xcc %llx\n", w * 61 + 7, h[w * 16] - t0, h[w * 16 + 8] - h[w * 16], h[w * 16 + 9]);
+            }
+#endif
             double cc = 0, cl = 0, ct = 0;
             int n2 = 0;
             for (int w = 0; w < 256; w++)

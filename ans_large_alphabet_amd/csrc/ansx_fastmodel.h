@@ -23,12 +23,11 @@
 
 #include "ansx_kernels.h"
 
-#ifdef ANSX_STAMPS  // development: per-phase wall-clock stamps of a few workgroups (printed by ansx_last_encode_stats)
-__device__ unsigned long long g_stamps[16 * 256];
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x % 64 == 7 && blockIdx.x / 64 < 256) g_stamps[(blockIdx.x / 64) * 16 + (i)] = wall_clock64(); } while (0)
-#else
+#ifdef ANSX_STAMPS_RF  // (development: the stamp rows belong to the ANSrfold remap kernel in this build)
+#undef STAMP
 #define STAMP(i) do { } while (0)
 #endif
+
 #define ANSX_FAST_GUARD 1e-9
 #define ANSX_CAND_SL 64u         // symbols per LDS stage (NT = 5: 12.5 KB per wave, three 4-wave workgroups per CU)
 #define ANSX_CAND_ROW (ANSX_CAND_SL + 1u)  // entries per block row (odd: rows start in different banks)

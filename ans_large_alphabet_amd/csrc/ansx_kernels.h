@@ -17,6 +17,18 @@
 
 #include "ansx_dev.h"
 
+#ifdef ANSX_STAMPS  // development: per-phase wall-clock stamps of a few workgroups (printed by ansx_last_encode_stats)
+__device__ unsigned long long g_stamps[16 * 256 + 16];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x % 61 == 7 && blockIdx.x / 61 < 256) g_stamps[(blockIdx.x / 61) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifdef ANSX_STAMPS_RF
+#define STAMP_RF(i) STAMP(i)
+#else
+#define STAMP_RF(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // per-block metadata (device)
 // ------------------------------------------------------------------------------------------
@@ -2703,6 +2715,7 @@ __global__ __launch_bounds__(256) void k_parse_prelude_par(const u8* __restrict_
 #ifndef ANSX_RING_CHK
 #define ANSX_RING_CHK 4
 #endif
+#define ANSX_DEC_SCRATCH 96u  // k_decode_rank: scan scratch + error flag between the tables and the stream area
 #define ANSX_RING_BYTES (128 * ANSX_RING_CHK)
 #define ANSX_RING_STRIDE (ANSX_RING_BYTES + 16)  // + 8 mirror bytes (ring bytes 0..7 once more) and padding to 16
 // end8 = end - 8: the decoder keeps its cursor biased by 8, so this is what its prefix sum yields
@@ -2782,7 +2795,10 @@ struct dec_lut_rank {
     __device__ __forceinline__ u32 bias() const { return (u32)(size_t)(__attribute__((address_space(3))) const void*)ep / 8u - 1u; }
     __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
     {
-        const uint2 wp = bwp[slot >> 5];
+        // The table starts at LDS address 0 (k_decode_rank has no static LDS and checks it): the entry's address is
+        // its byte offset, built from an integer so that no link-time base is added to it.
+        const u64 wpw = *(__attribute__((address_space(3))) const u64*)(size_t)((slot >> 2) & 0x3FF8u);
+        const uint2 wp = make_uint2((u32)wpw, (u32)(wpw >> 32));
         // bits [0, slot & 31] of the word: shift the rest out at the top (the shifter uses the low
         // five bits of ~slot = 31 - (slot & 31)); v_bcnt adds the biased prefix: the entry's address / 8
         const u32 r8 = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y;
@@ -2818,13 +2834,19 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     // the high word of the quotient is small: one 32x32->64 mad, and a 24-bit mad into its high word
     const u64 qs = st >> logM;
     u64 ns_;
+    bool rn;
+    u32 n_lo = 0, n_hi = 0;  // (rank form: the new state as two words -- packing them into a u64 and taking it apart
+                             // again below made hipcc copy the 64-bit product with a second, quarter-rate v_mad_u64_u32)
     if constexpr (LUT::WIDE) {
         ns_ = (u64)fr * qs + (u64)(slot - base);  // frames above 2^16: freq up to 2^27, quotient below 2^36
+        rn = active && (ns_ < Lb);
     } else {
         const u64 t = (u64)fr * (u32)qs + (u64)(slot - base);
-        ns_ = ((u64)((u32)(t >> 32) + __umul24(fr, (u32)(qs >> 32))) << 32) | (u32)t;
+        n_lo = (u32)t;
+        n_hi = (u32)(t >> 32) + __umul24(fr, (u32)(qs >> 32));
+        rn = active && n_hi == 0 && n_lo < (u32)Lb;  // Lb = 16 M <= 2^20 here
+        ns_ = 0;
     }
-    const bool rn = active && (ns_ < Lb);
     const u32 k = pv >> 30;
     const u32 cq = active ? ((k << qc.ql8) + (rn ? qc.four_pos : 0u)) : 0u;
     const u32 s1 = quad_add_dpp<0xB1>(cq);
@@ -2836,8 +2858,13 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     if (STREAM_LDS != 2) myp8 = myp8 < -8 ? -8 : myp8;
     const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp8);
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
-    if (rn) ns_ = (ns_ << 32) | hi;  // ans_fold.hpp:221-225
-    if (active) st = ns_;
+    if constexpr (LUT::WIDE) {
+        if (rn) ns_ = (ns_ << 32) | hi;  // ans_fold.hpp:221-225
+        if (active) st = ns_;
+    } else {
+        const u32 s_lo = rn ? hi : n_lo, s_hi = rn ? n_lo : n_hi;
+        if (active) st = ((u64)s_hi << 32) | s_lo;
+    }
     // the k exception bytes sit just below the renorm word (or at the top when there is none): the top k
     // bytes of lo resp. hi = that word, zero-extended to 64 bits, shifted right by 32 - 8k (0 for k = 0).
     // (Added, not OR-ed: an ANSrfold value has T subtracted and its low 8k bits are no longer zero.)
@@ -3095,8 +3122,8 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     u32 max_ns, u64 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
     u32* __restrict__ gflags)
 {
+    // (no static LDS in this kernel: the bitmap table sits at LDS address 0, so its reads need no base added)
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    __shared__ u32 sh_bad;
     const u32 tid = threadIdx.x, nt = blockDim.x;
     const u32 b = blockIdx.x;
     // Everything the table build needs from HBM is requested before anything is waited for: the block's parse
@@ -3127,6 +3154,9 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     off += (wmax * 8 + 15) & ~15u;
     uint2* ep = (uint2*)(smem + off);
     off += 2 * ((max_ns * 4 + 15) & ~15u);  // (same bytes as the host's 2 x rup(4 max_ns, 16))
+    u64* sh_scan = (u64*)(smem + off);        // 9 words of scan scratch + the block's error flag (ANSX_DEC_SCRATCH bytes)
+    u32& sh_bad = *(u32*)(smem + off + 80);
+    off += ANSX_DEC_SCRATCH;
     u32* lds_stream = (u32*)(smem + off);
     const u32 W = M >= 32 ? M / 32 : 1;
     // full block: all segments have g.ckpt ints (host-checked), each quad's first one is requested now
@@ -3147,7 +3177,11 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
     }
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
-    if (tid == 0) sh_bad = 0;
+    if (tid == 0) {
+        sh_bad = 0;
+        // dec_lut_rank::get addresses the bitmap table from LDS address 0
+        if ((u32)(size_t)(__attribute__((address_space(3))) void*)bwp != 0u) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+    }
     const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
     if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
     __syncthreads();
@@ -3158,7 +3192,6 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     // pays one global round trip per 4 nt symbols (one wave doing 64 symbols per round with the loads
     // inside the round was most of this kernel's time on 2300-symbol alphabets).
     {
-        __shared__ u64 sh_scan[8];
         u64 carry = 0;
         u32 bad = 0;
         for (u32 c0 = 0; c0 < ns; c0 += 4 * nt) {

@@ -208,6 +208,10 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
     u64* sel = (u64*)(smem_rh + 6 * (size_t)slots);                // [T]  (slots is a multiple of 4)
     const u32* src = in + (u64)b * g.block_ints;
     u32* dst = mapped + (u64)b * g.block_ints;
+    STAMP_RF(0);
+#ifdef ANSX_STAMPS_RF
+    const unsigned long long rf_t0 = wall_clock64();
+#endif
     for (u32 i = tid; i < slots; i += nt) keys[i] = ANSX_RF_EMPTY;
     for (u32 i = tid; i < slots / 2; i += nt) cnt32[i] = 0;
     if (tid == 0) {
@@ -226,6 +230,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         const u32 i = tid + q * nt;
         vals[q] = i < nb ? src[i] : 0u;
     }
+    STAMP_RF(1);
     u32 lmax = 0, ldistinct = 0;
     auto insert_one = [&](u32 v) {
         lmax = v > lmax ? v : lmax;
@@ -250,6 +255,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
     atomicMax(&sh_max, lmax);
     atomicAdd(&sh_cnt, ldistinct);
     __syncthreads();
+    STAMP_RF(2);
     if (sh_ovf) {  // optimistic table too small: a valid (all-zero, flag 0) block, and the call is repeated
         for (u32 i = tid; i < nb; i += nt) dst[i] = 0;
         if (tid == 0) {
@@ -355,7 +361,8 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
             if (n4) atomicAdd(&hist[4 < CAPC ? 4 : CAPC], n4);
         }
     }
-    const u32 cstar = find_bucket(CAPC + 1, T, true, &before);  // bin CAPC itself cannot be the answer: c* < CAPC
+    const u32 cstar = find_bucket(CAPC + 1, T, true, &before);
+    STAMP_RF(3);  // bin CAPC itself cannot be the answer: c* < CAPC
     const u32 G = before;            // values with count > c*: all selected
     const u32 K = T - G;             // K smallest values with count == c*
     __syncthreads();
@@ -382,6 +389,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         vstar = prefix;
     }
     __syncthreads();
+    STAMP_RF(4);
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
     // ---- collect the T selected (count, value) pairs: every wave counts its share, reserves it with ONE LDS
@@ -411,6 +419,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         }
     }
     __syncthreads();
+    STAMP_RF(5);
     // ---- sort them by (-count, value).  T <= 1024: one element per thread, bitonic network; a stage whose
     // partner distance is below 64 stays inside the wave (two shuffles, no LDS round trip, no barrier) -- 45 of
     // the 55 stages of a 1024-element sort
@@ -440,6 +449,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
     } else {
         lds_bitonic_sort<u64>(sel, T, tid, nt);
     }
+    STAMP_RF(6);
     for (u32 i = tid; i < slots / 2; i += nt) cnt32[i] = 0xFFFFFFFFu;  // rank 0xFFFF = not selected
     __syncthreads();
     u32* mf = mostfreq + (u64)b * T;
@@ -452,6 +462,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         atomicAnd(&cnt32[slot >> 1], ~(0xFFFFu << (16 * (slot & 1))) | (r << (16 * (slot & 1))));
     }
     __syncthreads();
+    STAMP_RF(7);
     // (the values are still in registers)
     auto remap_one = [&](u32 i, u32 v) {
         u32 slot = rf_slot(v, slots);
@@ -469,6 +480,19 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
     for (u32 q = 0; q < RF_VPT; q++)
         if (tid + q * nt < nb) remap_one(tid + q * nt, vals[q]);
     for (u32 i = tid + RF_VPT * nt; i < nb; i += nt) remap_one(i, src[i]);
+#ifdef ANSX_STAMPS_RF
+    __syncthreads();
+#endif
+    STAMP_RF(8);
+#ifdef ANSX_STAMPS_RF
+    if (threadIdx.x == 0) {
+        const unsigned long long d_ = wall_clock64() - rf_t0;
+        atomicMax(&g_stamps[4101], d_);
+        atomicAdd(&g_stamps[4102], d_);
+        if (d_ > 4000) atomicAdd(&g_stamps[4103], 1ull);
+    }
+    if (threadIdx.x == 0 && blockIdx.x % 61 == 7 && blockIdx.x / 61 < 256) g_stamps[(blockIdx.x / 61) * 16 + 9] = __builtin_amdgcn_s_getreg((23 << 0) | (0 << 6) | (31 << 11));
+#endif
     if (tid == 0) blk[b].flag = 1;
 }
 
@@ -479,7 +503,12 @@ __global__ __launch_bounds__(1024) void k_rfold_remap_hash(const u32* __restrict
     rfold_remap_hash_body(in, g, slots, mapped, mostfreq, blk, gflags);
 }
 // two workgroups per CU: 32 waves, 64 registers each
+#ifdef RF_NO_WPE
+__global__ __launch_bounds__(1024) void k_rfold_remap_hash2(
+#else
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rfold_remap_hash2(
+#endif
+
     const u32* __restrict__ in, ansx_geo g, u32 slots, u32* __restrict__ mapped, u32* __restrict__ mostfreq,
     ansx_blk* __restrict__ blk, u32* __restrict__ gflags)
 {

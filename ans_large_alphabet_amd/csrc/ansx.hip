@@ -1398,6 +1398,10 @@ int ansx_last_encode_stats(const ansx_ctx* c, ansx_encode_stats* out)
             }
             fprintf(stderr, "[stamps] %d workgroups, 100 MHz ticks per phase:", nn);
             for (int i = 1; i <= 10; i++) fprintf(stderr, " %d:%.0f", i, nn ? acc[i] / nn : 0.0);
+#ifdef ANSX_STAMPS_RF
+            { double a9 = 0, a10 = 0, a2 = 0; int m = 0; for (int w = 0; w < 256; w++) if (h[w*16+9] && h[w*16+10] && h[w*16+1]) { a9 += (double)(h[w*16+9]-h[w*16+1]); a10 += (double)(h[w*16+10]-h[w*16+9]); a2 += (double)(h[w*16+2]-h[w*16+10]); m++; }
+              if (m) fprintf(stderr, "  [insert split: clear %.0f count %.0f merge %.0f]", a9/m, a10/m, a2/m); }
+#endif
             fprintf(stderr, "\n");
 #ifdef ANSX_STAMPS_RF
             {

@@ -252,8 +252,16 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
     for (u32 q = 0; q < RF_VPT; q++)
         if (tid + q * nt < nb) insert_one(vals[q]);
     for (u32 i = tid + RF_VPT * nt; i < nb; i += nt) insert_one(src[i]);  // (fewer than 1024 threads)
-    atomicMax(&sh_max, lmax);
-    atomicAdd(&sh_cnt, ldistinct);
+    // (one atomic per wave: 1024 threads on the same two words queue up in the LDS unit)
+    for (int o = 32; o > 0; o >>= 1) {
+        const u32 om = (u32)__shfl_xor((int)lmax, o);
+        lmax = om > lmax ? om : lmax;
+        ldistinct += (u32)__shfl_xor((int)ldistinct, o);
+    }
+    if ((tid & 63u) == 0) {
+        atomicMax(&sh_max, lmax);
+        atomicAdd(&sh_cnt, ldistinct);
+    }
     __syncthreads();
     STAMP_RF(2);
     if (sh_ovf) {  // optimistic table too small: a valid (all-zero, flag 0) block, and the call is repeated

@@ -215,6 +215,7 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     g.f = (u32)f;
     g.kind = (u32)kind;
     g.pa = pa ? 1u : 0u;
+    g.payload_bytes = 0;  // (set by decode_dev from the container header)
     g.map = kind == ANSX_MSB ? map_msb() : (kind == ANSX_INT ? map_int() : map_fold((u32)f));
     P->g = g;
     // symbol-array stride: the reference's MAX_SIGMA (ans_fold.hpp:70; ans_msb.hpp:28 has 1280)
@@ -360,22 +361,29 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
     // per-block stream sizes + their sums per 64 blocks, published by the encoder for k_assemble
-    const size_t ngroups = ((size_t)NB + 63) / 64;
+    const size_t ngroups = (((size_t)NB + 63) / 64 + 1) & ~(size_t)1;  // (an even count: the sums end on a 16-byte boundary)
     if ((rc = ensure(c, c->sizes, ngroups * 8 + (size_t)NB * 4))) return rc;
     unsigned long long* enc_gsums = (unsigned long long*)c->sizes.p;
     u32* enc_sizes = (u32*)((u8*)c->sizes.p + ngroups * 8);
-    HIPCHK(c, hipMemsetAsync(enc_gsums, 0, ngroups * 8, s));
     u32* gflags = (u32*)c->misc.p;
     u64* result = (u64*)((u8*)c->misc.p + 16);
     u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
     ansx_blk* blk = (ansx_blk*)c->blk.p;
     u32* hist = (u32*)c->hist.p;
 
-    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, s));
-    HIPCHK(c, hipMemsetAsync(blk, 0, (size_t)NB * sizeof(ansx_blk), s));
-    // header / index / restart-point area: unused slots (short last block) and alignment
-    // padding are defined to be zero, so equal inputs give byte-identical containers
-    if (!P.plain) HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)P.lay.payload_off, s));
+    {
+        // flag words, size sums, block metadata, and the container's header / index / restart-point area: unused
+        // slots (short last block) and alignment padding are defined to be zero, so equal inputs give
+        // byte-identical containers
+        static_assert(sizeof(ansx_blk) % 16 == 0, "zeroed 16 bytes at a time");
+        ansx_zero4 Z;
+        Z.p[0] = (uint4*)c->misc.p, Z.n16[0] = 4;
+        Z.p[1] = (uint4*)enc_gsums, Z.n16[1] = ngroups / 2;
+        Z.p[2] = (uint4*)blk, Z.n16[2] = (u64)NB * (sizeof(ansx_blk) / 16);
+        Z.p[3] = (uint4*)d_out, Z.n16[3] = P.plain ? 0 : (u64)P.lay.payload_off / 16;
+        const u64 tot = Z.n16[0] + Z.n16[1] + Z.n16[2] + Z.n16[3];
+        LAUNCH(c, "k_begin_encode", k_begin_encode, (u32)std::min<u64>(2048, (tot + 255) / 256), 256, 0, s, Z);
+    }
 
     if ((rc = ensure(c, c->nearlist, (size_t)ANSX_NEAR_CAP * 4))) return rc;
     const u32* src = d_in;
@@ -705,7 +713,7 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
     if ((rc = ensure(c, c->scratch, (size_t)NB * scr_stride))) return rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)NB + 1)))) return rc;
-    const size_t ngroups = ((size_t)NB + 63) / 64;
+    const size_t ngroups = (((size_t)NB + 63) / 64 + 1) & ~(size_t)1;
     if ((rc = ensure(c, c->sizes, ngroups * 8 + (size_t)NB * 4))) return rc;
     unsigned long long* enc_gsums = (unsigned long long*)c->sizes.p;
     u32* enc_sizes = (u32*)((u8*)c->sizes.p + ngroups * 8);
@@ -1278,13 +1286,24 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         ck_off = (const u32*)(d_in + P.lay.ckoff_off);
         payload_off = H.payload_offset;
         in_bytes_payload = H.payload_bytes;
-        LAUNCH(c, "k_validate_index", k_validate_index, (P.g.nblocks + 255) / 256, 256, 0, s, P.g, boff,
-            H.payload_bytes, gflags);
-        // the index must be sane before any block is touched
-        HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
-        max_block_bytes = c->h_pin[ANSX_G_PAD];
+        P.g.payload_bytes = H.payload_bytes;  // every parser validates the two index entries of its own block (index_entry_ok)
+        // The ring decoder needs nothing else from the index: no validation kernel, no read-back.  The staged /
+        // straight-from-HBM forms size their LDS from the largest block stream, which only the index knows.
+        const size_t rs_probe = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16) + ANSX_DEC_SCRATCH;
+        const bool ring_certain = !P.g.pa && maxM <= 65536u && P.g.ckpt != 0 && P.g.block_ints % P.g.ckpt == 0 && P.g.ckpt % 4 == 0
+            && c->dbg.decode_mode != 2 && !c->dbg.decode_table
+            && rs_probe + (size_t)(std::min<u32>(256u, (u32)rup((size_t)geo_nseg(P.g.block_ints, P.g.ckpt) * 4, 64)) / 4) * ANSX_RING_STRIDE + 16 <= 60 * 1024;
+        if (ring_certain) {
+            max_block_bytes = (u32)std::min<size_t>(0x7FFFFFFFu, block_bound((int)P.g.kind, f, P.g.block_ints, false));  // (=> never "staged fits")
+        } else {
+            LAUNCH(c, "k_validate_index", k_validate_index, (P.g.nblocks + 255) / 256, 256, 0, s, P.g, boff,
+                H.payload_bytes, gflags);
+            // the index must be sane before any block is touched
+            HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->h_pin[ANSX_G_ERR]) return flags_to_status(c->h_pin[ANSX_G_ERR]);
+            max_block_bytes = c->h_pin[ANSX_G_PAD];
+        }
     }
     const u32* hints = P.plain ? nullptr : (const u32*)(d_in + P.lay.hint_off);
     const uint4* pa_info = nullptr;

@@ -246,7 +246,20 @@ struct ansx_geo {
     u32 kind;        // 0 fold, 1 rfold, 2 msb, 3 int
     u32 pa;          // 1: per-block alphabet compaction (ansx_pa.h)
     ansx_map map;    // value <-> symbol map of this codec
+    u64 payload_bytes;  // decode: bytes of block streams behind the container's payload offset (0 on the encode side)
 };
+
+// One entry pair of a container's block index, as untrusted as the payload: the same conditions k_validate_index
+// applies to the whole index, for the one block a parser is about to touch (a reference stream has at least 2
+// prelude bytes + one interpolative word + 32 state bytes; with compaction a one-value block is just its header).
+ANSX_HD bool index_entry_ok(const ansx_geo& g, u32 b, u64 a, u64 e)
+{
+    const u64 min_bytes = g.pa ? 8 : 38;
+    bool bad = (e < a) || (e - a) < min_bytes || (e - a) >= (1ull << 31) || e > g.payload_bytes;
+    if (b == 0 && a != 0) bad = true;
+    if (b == g.nblocks - 1 && e != g.payload_bytes) bad = true;
+    return !bad;
+}
 
 ANSX_HD u32 geo_block_n(const ansx_geo& g, u32 b)
 {

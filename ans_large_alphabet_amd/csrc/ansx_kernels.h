@@ -86,6 +86,23 @@ __device__ __forceinline__ bool ansx_near_threshold(double XH, double thr, doubl
 }
 enum { ANSX_ATTEMPTS = 8 };  // frame sizes tried per batch
 
+// K0: everything an encode call needs zeroed, in one launch instead of four memsets (each a few microseconds of an
+// otherwise idle stream): the call's flag words, the per-64-block size sums, the per-block metadata and the
+// container's header / index / restart-point area (unused slots and padding are defined to be zero).
+// Regions are 16-byte aligned; lengths in 16-byte units.
+struct ansx_zero4 {
+    uint4* p[4];
+    u64 n16[4];
+};
+__global__ __launch_bounds__(256) void k_begin_encode(ansx_zero4 Z)
+{
+    const u64 stride = (u64)gridDim.x * 256;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < Z.n16[r]; i += stride) Z.p[r][i] = z;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: folded-symbol histogram.  One workgroup per chunk of a block; LDS bins; coalesced 16 B
 // loads.  Replaces the first pass of ans_fold_encode<f>::create (ans_fold.hpp:74-78).
@@ -2216,9 +2233,14 @@ __device__ __forceinline__ parse_hdr parse_header(const u8* __restrict__ cont, c
 {
     const u32 T = fold_T(g.f);
     u32 err = 0, ns = 0, logM = 0, flag = 0;
-    const u64 boff = block_off[b];
+    const u64 boff = block_off[b], boff1 = block_off[b + 1];
+    if (g.payload_bytes != 0 && !index_entry_ok(g, b, boff, boff1)) {  // (single-stream mode has no index: payload_bytes 0)
+        parse_hdr Hb;
+        Hb.err = 1, Hb.ns = 1, Hb.logM = 0, Hb.flag = 0, Hb.pos = 0, Hb.sbytes = 0, Hb.stream = cont;
+        return Hb;
+    }
     const u8* stream = cont + payload_off + boff;
-    const u32 sbytes = (u32)(block_off[b + 1] - boff);
+    const u32 sbytes = (u32)(boff1 - boff);
     u32 pos = 0;
     if (pa_info != nullptr) {
         const uint4 pi = pa_info[b];

@@ -240,6 +240,35 @@ def config1_rows(A):
     return out
 
 
+def compaction_rows(torch, A, ctx, device, n=64 * (1 << 20)):
+    """bits/int and rate with and without the per-block alphabet compaction on two inputs: the headline Zipf list
+    (every block sees ~2500 distinct values: listing them costs more than folding their low bytes) and a list whose
+    blocks each use a small alphabet of LARGE values (document-local vocabularies: 200 distinct 24-bit values per
+    16 Ki-int block, Zipf-ranked) -- the case the reference's pseudo_adaptive harness is about."""
+    import numpy as np
+
+    rng = np.random.default_rng(SEED)
+    nblk = n // 16384
+    vocab = rng.integers(1 << 16, 1 << 24, size=(nblk, 200), dtype=np.uint32)
+    ranks = np.minimum(rng.zipf(1.3, size=(nblk, 16384)) - 1, 199)
+    local = np.take_along_axis(vocab, ranks, axis=1).reshape(-1).astype(np.uint32)
+    inputs = {"zipf20s1.2": None, "block-local vocabularies (200 distinct 24-bit values per block, Zipf(1.3) ranks)": local}
+    rows = []
+    for name, host in inputs.items():
+        if host is None:
+            d_in = gen_input(torch, A, ctx, "zipf20s1.2", n, SEED, device)
+        else:
+            d_in = torch.from_numpy(host.view("int32")).to(device)
+        for label, cn, compact in (("ANSfold-1", "fold", False), ("ANSfold-1 + compaction", "fold", True), ("ANSint + compaction", "int", True)):
+            r = run_single(torch, A, ctx, device, cn, 1 if cn == "fold" else 0, name, n, 3, 2, d_in=d_in, compact=compact,
+                           block=8192 if cn == "int" else 0, profile=False)
+            rows.append({"input": name, "codec": label, "bits_per_int": r["bits_per_int"], "value": r["value"], "unit": "Mints/s",
+                         "roundtrip_ok": r["roundtrip_ok"]})
+        del d_in
+        torch.cuda.empty_cache()
+    return rows
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this workload
     (profiles/*_hbm_traffic_pmc.json, one per profiled configuration: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate passes, gfx950
@@ -713,7 +742,7 @@ def main():
             extra.append({"baseline_config": "config 5 fallback", "error": repr(exc)})
 
     # ---- speed against size: block length / restart interval (the two options that decide the operating point)
-    frontier = config1 = None
+    frontier = config1 = compaction = None
     if rank == 0 and world == 1 and not args.no_extra and not args.no_frontier:
         frontier = []
         for blk_, ck_ in ((16384, 512), (16384, 1024), (16384, 2048), (32768, 1024)):
@@ -729,6 +758,11 @@ def main():
             config1 = config1_rows(A)
         except Exception as exc:  # noqa: BLE001
             config1 = {"error": repr(exc)}
+        # where the per-block alphabet compaction (src/pseudo_adaptive.cpp:85-130) pays and where it does not
+        try:
+            compaction = compaction_rows(torch, A, ctx, device)
+        except Exception as exc:  # noqa: BLE001
+            compaction = {"error": repr(exc)}
 
     multi_gpu = "single GPU"
     if world > 1:
@@ -771,7 +805,7 @@ def main():
             "near_threshold_decisions": stats["near_threshold_decisions"], "encode_path": stats["path"],
             "roofline": roofline, "cpu_baseline": cpu, "gpu_rates": gpu_rates, "cpu_all_cores": cpu_all,
             "host_buffer_api": host_api, "kernels": kernels, "extra_configs": extra, "frontier": frontier,
-            "config1_table10": config1,
+            "config1_table10": config1, "alphabet_compaction": compaction,
             "workspace_mb": ctx.workspace_bytes() / 1e6,
         }
         if cpu:

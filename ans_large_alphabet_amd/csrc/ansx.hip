@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is resolved at first use (ansx_gather_containers)
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,9 @@ struct ansx_ctx {
     // model kernel and of the LDS-table encoder without a mid-call round trip (see encode_dev).
     std::map<u64, u32> ns_hint;
     std::map<u64, u32> rf_hint;  // rfold: most distinct values per block seen per geometry (optimistic hash-table size)
+    // header of the last container decoded per (kind, fidelity, n, bytes): the next decode of that shape is launched
+    // on it without waiting for the header to come back, and a one-thread kernel compares it with the real one
+    std::map<std::array<u64, 4>, ansx_container_header> hdr_cache;
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
     const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
     const u32* cur_src = nullptr;    // set by encode_general: the ints the model kernels saw (the input, or its remapped form)
@@ -1162,6 +1166,17 @@ __global__ void k_selftest_log2(const double* __restrict__ in, double* __restric
     if (i < n) out[i] = ansx_log2_portable(in[i]);
 }
 
+#define ANSX_G_HDR_BIT 9u  // gflags[ANSX_G_ERR]: the container header is not the one this decode was launched on
+__global__ void k_check_header(const u8* __restrict__ cont, ansx_container_header want, u32* __restrict__ gflags)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const u32* a = (const u32*)cont;
+    const u32* w = (const u32*)&want;
+    u32 diff = 0;
+    for (int i = 0; i < 16; i++) diff |= a[i] ^ w[i];
+    if (diff) atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_HDR_BIT);
+}
+
 __global__ void k_validate_index(ansx_geo g, const u64* __restrict__ boff, u64 payload_bytes,
     u32* __restrict__ gflags)
 {
@@ -1194,9 +1209,12 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
 }
 
 int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u32* d_out,
-    hipStream_t s)
+    hipStream_t s, bool allow_spec = true)
 {
     Plan P = Pin;
+    bool spec = false;
+    ansx_container_header Hspec;
+    const std::array<u64, 4> hkey = { (u64)Pin.g.kind, (u64)Pin.g.f, (u64)Pin.g.n, (u64)in_bytes };
     int rc;
     if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)P.g.nblocks + 1)))) return rc;
     u32* gflags = (u32*)c->misc.p;
@@ -1257,9 +1275,20 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     } else {
         u8* hp = (u8*)c->h_pin + 64;
         if (in_bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
-        HIPCHK(c, hipMemcpyAsync(hp, d_in, sizeof(ansx_container_header), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
         ansx_container_header H;
+        const auto hit = c->hdr_cache.find(hkey);
+        if (allow_spec && hit != c->hdr_cache.end()) {
+            // Same shape as a container decoded before: launch on that header now, verify it on the device
+            // (k_check_header); a different header repeats the call the slow way.  Every kernel treats header-derived
+            // sizes as untrusted anyway (index entries, restart points and hints are bounds-checked against them).
+            H = hit->second;
+            memcpy(hp, &H, sizeof(H));
+            spec = true;
+            Hspec = H;
+        } else {
+            HIPCHK(c, hipMemcpyAsync(hp, d_in, sizeof(ansx_container_header), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
         if ((rc = parse_header(hp, in_bytes, &H))) return rc;
         if ((H.kind & 0xFFu) != P.g.kind || H.fidelity != f || H.n != P.g.n) return ANSX_ERR_FORMAT;
         // the container, not the caller's options, defines the geometry
@@ -1293,6 +1322,10 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         const bool ring_certain = !P.g.pa && maxM <= 65536u && P.g.ckpt != 0 && P.g.block_ints % P.g.ckpt == 0 && P.g.ckpt % 4 == 0
             && c->dbg.decode_mode != 2 && !c->dbg.decode_table
             && rs_probe + (size_t)(std::min<u32>(256u, (u32)rup((size_t)geo_nseg(P.g.block_ints, P.g.ckpt) * 4, 64)) / 4) * ANSX_RING_STRIDE + 16 <= 60 * 1024;
+        if (spec && !ring_certain) {  // (a read-back follows anyway: nothing to gain from the cached header)
+            c->hdr_cache.erase(hkey);
+            return decode_dev(c, Pin, d_in, in_bytes, d_out, s, false);
+        }
         if (ring_certain) {
             max_block_bytes = (u32)std::min<size_t>(0x7FFFFFFFu, block_bound((int)P.g.kind, f, P.g.block_ints, false));  // (=> never "staged fits")
         } else {
@@ -1323,9 +1356,21 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     if (rc) return rc;
     if (P.g.pa)
         LAUNCH(c, "k_pa_unmap", k_pa_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, pa_info, d_out, gflags);
+    if (spec) LAUNCH(c, "k_check_header", k_check_header, 1, 64, 0, s, d_in, Hspec, gflags);
     HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    return flags_to_status(c->h_pin[ANSX_G_ERR]);
+    if (spec && (c->h_pin[ANSX_G_ERR] & (1u << ANSX_G_HDR_BIT))) {
+        c->hdr_cache.erase(hkey);
+        return decode_dev(c, Pin, d_in, in_bytes, d_out, s, false);
+    }
+    const int st = flags_to_status(c->h_pin[ANSX_G_ERR]);
+    if (!P.plain && !spec && st == ANSX_OK) {
+        ansx_container_header Hc;
+        memcpy(&Hc, (u8*)c->h_pin + 64, sizeof(Hc));
+        c->hdr_cache[hkey] = Hc;
+        if (c->hdr_cache.size() > 64) c->hdr_cache.erase(c->hdr_cache.begin());
+    }
+    return st;
 }
 
 }  // namespace

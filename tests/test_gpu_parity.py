@@ -503,6 +503,42 @@ def test_rccl_gather_entry_point_from_cpp(tmp_path):
     assert r.returncode == 0 and "gather_selftest OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
 
 
+def test_decode_on_a_remembered_header_is_verified(A, oracle_built):
+    """The second decode of a container shape (kind, fidelity, n, bytes) is launched on the header remembered from the
+    first without waiting for the real one; a kernel compares the two and a difference repeats the call the slow way:
+    another container of the same size, a changed but valid header, a corrupt header."""
+    n = 6 * 4096 + 17
+    a = ol.gen_inputs("zipf20s1.2", n, seed=5)
+    c = A.Context(0)
+    codec = A.ANSfold(1, ctx=c, block_ints=4096, ckpt_interval=512)
+    ca = codec.encode(a)
+    assert np.array_equal(codec.decode(ca, n), a)      # remembers the header
+    assert np.array_equal(codec.decode(ca, n), a)      # launched on it
+    # same bytes and shape, other restart interval in the header of a copy -> a header the cached one does not match
+    other = A.ANSfold(1, ctx=c, block_ints=4096, ckpt_interval=1024)
+    b = ol.gen_inputs("uniform12", n, seed=6)
+    for _ in range(200):                              # a second container with the SAME byte count
+        cb = other.encode(b)
+        if cb.size == ca.size:
+            break
+        b = np.concatenate([b[1:], b[:1]])
+        if cb.size < ca.size:
+            b = b.copy()
+            b[0] = (int(b[0]) * 7 + 12345) % (1 << 20)
+    if cb.size == ca.size:
+        assert np.array_equal(other.decode(cb, n), b)
+        assert np.array_equal(codec.decode(ca, n), a)
+    bad = ca.copy()
+    bad[32] ^= 1                                      # nblocks: no longer the remembered header, and not a valid one
+    with pytest.raises(A.AnsxError):
+        codec.decode(bad, n)
+    grown = ca.copy()
+    grown[40] ^= 0xFF                                 # max_nsyms 526 -> 753: another header, still a valid bound
+    assert np.array_equal(codec.decode(grown, n), a)
+    assert np.array_equal(codec.decode(ca, n), a)
+    c.close()
+
+
 def test_native_merge_of_compacted_containers_and_bad_parts(A, ctx):
     """Containers with per-block alphabet compaction (kind word | 0x100: ANSint, ANSfold + compact) merge like the
     others; a part whose header does not describe its own layout (block count, payload offset) is refused

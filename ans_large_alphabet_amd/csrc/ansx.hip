@@ -61,6 +61,7 @@ struct ansx_ctx {
     // header of the last container decoded per (kind, fidelity, n, bytes): the next decode of that shape is launched
     // on it without waiting for the header to come back, and a one-thread kernel compares it with the real one
     std::map<std::array<u64, 4>, ansx_container_header> hdr_cache;
+    std::map<u32, DevBuf> geo;   // tree nodes of the interpolative code per alphabet size, tabulated per symbol-array size (<= 4096)
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
     const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
     const u32* cur_src = nullptr;    // set by encode_general: the ints the model kernels saw (the input, or its remapped form)
@@ -359,6 +360,15 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         if ((rc = ensure(c, c->log2lut, (size_t)65536 * sizeof(ansx_log2_ent)))) return rc;
         LAUNCH(c, "k_build_log2_lut", k_build_log2_lut, 256, 256, 0, s, (ansx_log2_ent*)c->log2lut.p);
     }
+    const uint2* geo = nullptr;
+    if (NSP <= 4096) {  // tree nodes of the prelude's interpolative code for every alphabet size up to NSP, once per context
+        DevBuf& gb = c->geo[NSP];
+        if (!gb.p) {
+            if ((rc = ensure(c, gb, ((size_t)NSP * (NSP + 1) / 2 + 8) * 8))) return rc;
+            LAUNCH(c, "k_build_interp_geo", k_build_interp_geo, NSP, 256, 0, s, NSP, (uint2*)gb.p);
+        }
+        geo = (const uint2*)gb.p;
+    }
     if ((rc = ensure(c, c->blk, (size_t)NB * sizeof(ansx_blk)))) return rc;
     if ((rc = ensure(c, c->table, (size_t)NB * NSP * sizeof(ansx_enc_entry)))) return rc;
     if ((rc = ensure(c, c->tab32, (size_t)NB * NSP * 4))) return rc;
@@ -521,12 +531,12 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         const size_t fl = (size_t)fcap * 12 + 64;
         if (NSP <= 1024) {
             LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p);
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo);
         } else {
             if (fl > 48 * 1024)
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
             LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p);
+                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo);
         }
         max_logM = 16;
         max_ns = ns_cap;
@@ -567,17 +577,17 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     } else if (NSP <= 1024 && max_logM <= 16) {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<4>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints, pre_cap);
+            (u64)scr_stride, mostfreq, hints, pre_cap, geo);
     } else if (NSP <= 4096 && max_logM <= 16) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)((size_t)pre_cap * 12 + 64)));
         LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints, pre_cap);
+            (u64)scr_stride, mostfreq, hints, pre_cap, geo);
     } else {
         LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints, NSP);
+            (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr);
     }
     // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
     // alphabet / frame actually produced, read back above).
@@ -1527,6 +1537,8 @@ void ansx_destroy(ansx_ctx* c)
         &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes, &c->nearlist, &c->force };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (auto& kv : c->geo)
+        if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& r : c->recs) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);

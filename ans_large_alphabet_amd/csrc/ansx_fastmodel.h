@@ -271,7 +271,8 @@ template <int IPT>
 __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 NT, const uint2* __restrict__ pairs,
     const uint4* __restrict__ srank, const u32* __restrict__ attMeta, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard, const double* __restrict__ lg2i)
+    u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard, const double* __restrict__ lg2i,
+    const uint2* __restrict__ geo)
 {
     static_assert(IPT % 4 == 0, "table rows are written 16 bytes at a time");
     static_assert(ANSX_FIN_LUT == 512, "two table entries per thread");
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     __syncthreads();  // frq (= bits) has been read by everyone; inc[] is complete
     STAMP(9);
 #ifndef FIN_NO_PRELUDE
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints);
+    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);
 #endif
     STAMP(10);
 }

@@ -977,13 +977,18 @@ template <typename T> __device__ __forceinline__ T block_excl_scan(T v, T* wsum,
     return wsum[tid >> 6] + incl - v;
 }
 
-__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, u64 u, u32 i)
+// The tree node of item i in the interpolative code of ns items: the run [a, a + n) whose middle it is, and its
+// pre-order rank.  A function of (ns, i) only -- k_build_interp_geo tabulates it per context for alphabets up to 4096
+// slots (geo: triangular, row ns at ns (ns - 1) / 2, entry = {a | n << 16, rank}); the descent is the fallback.
+struct ansx_node {
+    u32 a, n, rank;
+};
+__device__ __forceinline__ ansx_node interp_node(u32 ns, u32 i)
 {
     u32 a = 0, n = ns, rank = 0;
-    u32 h, mid;
     for (;;) {
-        h = (n + 1) >> 1;
-        mid = a + h - 1;
+        const u32 h = (n + 1) >> 1;
+        const u32 mid = a + h - 1;
         if (i == mid) break;
         if (i < mid) {
             n = h - 1;
@@ -994,6 +999,32 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
             n -= h;
         }
     }
+    return ansx_node{ a, n, rank };
+}
+ANSX_HD u64 interp_geo_row(u32 ns) { return (u64)ns * (ns - 1) / 2; }
+__global__ __launch_bounds__(256) void k_build_interp_geo(u32 max_ns, uint2* __restrict__ geo)
+{
+    const u32 ns = blockIdx.x + 1;  // 1 .. max_ns
+    if (ns > max_ns) return;
+    uint2* row = geo + interp_geo_row(ns);
+    for (u32 i = threadIdx.x; i < ns; i += 256) {
+        const ansx_node nd = interp_node(ns, i);
+        row[i] = make_uint2(nd.a | (nd.n << 16), nd.rank);
+    }
+}
+
+__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, u64 u, u32 i,
+    const uint2* __restrict__ geo_row = nullptr)
+{
+    u32 a, n, rank;
+    if (geo_row != nullptr) {
+        const uint2 e = geo_row[i];
+        a = e.x & 0xFFFFu, n = e.x >> 16, rank = e.y;
+    } else {
+        const ansx_node nd = interp_node(ns, i);
+        a = nd.a, n = nd.n, rank = nd.rank;
+    }
+    const u32 h = (n + 1) >> 1, mid = i;
     const u64 n1 = h - 1, n2 = n - h;
     const u64 low = (a == 0) ? 1ull : (u64)inc[a - 1] + 2ull;          // parent v + 1
     const u64 high = (a + n == ns) ? (u + 1ull) : (u64)inc[a + n];     // parent v - 1
@@ -1035,8 +1066,9 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
 template <int IPT, bool PA = false>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
     u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
-    u64 uni = 0, u32* __restrict__ hints = nullptr)
+    u64 uni = 0, u32* __restrict__ hints = nullptr, const uint2* __restrict__ geo = nullptr)
 {
+    const uint2* const geo_row = (geo != nullptr && ns >= 1) ? geo + interp_geo_row(ns) : nullptr;  // (tabulated tree nodes)
     constexpr bool SMALL = IPT > 0;
     const u64 u = PA ? uni : ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
@@ -1046,13 +1078,13 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
             const u32 i = tid + 256 * j;
             mine[j].len = 0;
             if (i < ns) {
-                mine[j] = interp_item(inc, ns, u, i);
+                mine[j] = interp_item(inc, ns, u, i, geo_row);
                 off[mine[j].rank] = mine[j].len;
             }
         }
     } else {
         for (u32 i = tid; i < ns; i += 256) {
-            ansx_code c = interp_item(inc, ns, u, i);
+            ansx_code c = interp_item(inc, ns, u, i, geo_row);
             off[c.rank] = c.len;
         }
     }
@@ -1111,7 +1143,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
-        for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i));
+        for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i, geo_row));
     }
     __syncthreads();
     const u32 nbytes = nwords * 4;
@@ -1167,7 +1199,7 @@ template <int IPT>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ hints, u32 cap)
+    u32* __restrict__ hints, u32 cap, const uint2* __restrict__ geo)
 {
     // cap = words per LDS array: NSP, or on an optimistic call the alphabet hint the whole call is sized for (a
     // 2300-symbol alphabet then takes 28 KB instead of the 48 KB of its 4096 slots: 5 instead of 3 workgroups per
@@ -1219,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         __threadfence_block();
     }
     __syncthreads();
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints);
+    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -474,8 +474,10 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         if ((rc = ensure(c, c->hterm, (size_t)NB * NSP * 8))) return rc;
         hterm = (double*)c->hterm.p;
     }
-    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, h_in_hist ? (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (size_t)NSP * 8 + 80 : (size_t)NSP * 4, s, src, g, chunk, cpb,
-        NSP, hist, hterm, (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
+    // (fast path: H is a tree sum in registers, no LDS row of terms)
+    const size_t hist_lds = !h_in_hist ? (size_t)NSP * 4 : (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (fast ? 0 : (size_t)NSP * 8 + 80);
+    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, hist_lds, s, src, g, chunk, cpb, NSP, hist, hterm,
+        (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)

@@ -221,6 +221,71 @@ ANSX_D u32 quad_incl_scan(u32 c, u32 ql, u32* total)
     return s2;
 }
 
+// Wave-wide (64 lanes) inclusive scan and reductions over DPP row shifts and row broadcasts -- six VALU moves instead
+// of six ds_bpermute round trips through the LDS pipe (each ~100 cycles of latency on a dependent chain, which is what
+// the per-block kernels with one or two waves in flight spend their time on).  Same explicit-asm form as quad_perm
+// above, for the same reason.  Lanes switched off by EXEC and lanes outside a row contribute the identity (all-zero
+// bits: 0, +0.0), so the caller may be inside divergent code as long as the lanes that matter are on.
+//   steps 0..3: row_shr:1,2,4,8 (scan inside each row of 16); 4: row_bcast:15 into rows 1,3; 5: row_bcast:31 into
+//   rows 2,3 -- the sequence LLVM's own atomic optimiser emits for gfx9.
+#define ANSX_DPP_ASM(CTRL, ROWM)                                                                         \
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 " CTRL " row_mask:" ROWM " bank_mask:0xf" : "+v"(r) : "v"(v))
+template <int STEP> ANSX_D u32 dpp_scan_mov(u32 v)
+{
+    u32 r = 0;
+    if constexpr (STEP == 0) ANSX_DPP_ASM("row_shr:1", "0xf");
+    else if constexpr (STEP == 1) ANSX_DPP_ASM("row_shr:2", "0xf");
+    else if constexpr (STEP == 2) ANSX_DPP_ASM("row_shr:4", "0xf");
+    else if constexpr (STEP == 3) ANSX_DPP_ASM("row_shr:8", "0xf");
+    else if constexpr (STEP == 4) ANSX_DPP_ASM("row_bcast:15", "0xa");
+    else ANSX_DPP_ASM("row_bcast:31", "0xc");
+    return r;
+}
+template <int STEP, typename T> ANSX_D T dpp_scan_mov_t(T v)
+{
+    if constexpr (sizeof(T) == 4) {
+        const u32 r = dpp_scan_mov<STEP>(__builtin_bit_cast(u32, v));
+        return __builtin_bit_cast(T, r);
+    } else {
+        static_assert(sizeof(T) == 8, "32- or 64-bit values");
+        const u64 b = __builtin_bit_cast(u64, v);
+        const u32 lo = dpp_scan_mov<STEP>((u32)b), hi = dpp_scan_mov<STEP>((u32)(b >> 32));
+        const u64 r = (u64)lo | ((u64)hi << 32);
+        return __builtin_bit_cast(T, r);
+    }
+}
+struct ansx_op_add { template <typename T> ANSX_D T operator()(T a, T b) const { return a + b; } };
+struct ansx_op_max { template <typename T> ANSX_D T operator()(T a, T b) const { return a > b ? a : b; } };
+struct ansx_op_or { template <typename T> ANSX_D T operator()(T a, T b) const { return a | b; } };
+template <typename T, typename Op = ansx_op_add> ANSX_D T wave_incl_scan(T v, Op op = Op())
+{
+    v = op(v, dpp_scan_mov_t<0>(v));
+    v = op(v, dpp_scan_mov_t<1>(v));
+    v = op(v, dpp_scan_mov_t<2>(v));
+    v = op(v, dpp_scan_mov_t<3>(v));
+    v = op(v, dpp_scan_mov_t<4>(v));
+    v = op(v, dpp_scan_mov_t<5>(v));
+    return v;
+}
+// lane 63's value in every lane (a scalar broadcast)
+template <typename T> ANSX_D T wave_last(T v)
+{
+    if constexpr (sizeof(T) == 4) {
+        const u32 r = (u32)__builtin_amdgcn_readlane((int)__builtin_bit_cast(u32, v), 63);
+        return __builtin_bit_cast(T, r);
+    } else {
+        const u64 b = __builtin_bit_cast(u64, v);
+        const u64 r = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)b, 63) |
+                      ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(b >> 32), 63) << 32);
+        return __builtin_bit_cast(T, r);
+    }
+}
+// reductions over the (active lanes of the) wave, result in every lane.  The order of additions is the scan's, not a
+// butterfly's: only for integers and for floating-point sums that sit behind a guard band.
+template <typename T> ANSX_D T wave_sum(T v) { return wave_last(wave_incl_scan(v, ansx_op_add())); }
+template <typename T> ANSX_D T wave_max(T v) { return wave_last(wave_incl_scan(v, ansx_op_max())); }
+template <typename T> ANSX_D T wave_or(T v) { return wave_last(wave_incl_scan(v, ansx_op_or())); }
+
 // byte-granular global accesses.  gfx950 global memory supports unaligned dword/dwordx2
 // accesses (HSA unaligned access mode); the packed structs make hipcc emit single
 // global_load/store instructions with align 1.

@@ -104,10 +104,7 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
         sp[c] = srank + srank_chunk(NSP, NT, live[c] ? bb[c] : wb0, 0u, t);  // + batch * NT
         row[c] = cand_lds + (c * BPW + (bl < BPW ? bl : BPW - 1u)) * ANSX_CAND_ROW;
     }
-    for (int o = 32; o > 0; o >>= 1) {  // the wave runs as long as its longest block
-        const u32 x = (u32)__shfl_xor((int)wsig, o);
-        wsig = x > wsig ? x : wsig;
-    }
+    wsig = wave_max(wsig);  // the wave runs as long as its longest block
     // staging: the wave's 64 lanes fetch SL pairs of each of its blocks (coalesced) one stage ahead of the
     // recurrence and turn fs_rem into its reciprocal on the way into LDS
     constexpr u32 NITER = rows * (ANSX_CAND_SL / 64u);
@@ -315,7 +312,8 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     // first chunk of this lane for the wave's one or two candidates (chunk index lane < NSP / 8 always: NSP >= 512)
     const u32 t0 = wv, t1 = wv + 4u;
     const chunk k0 = load_chunk(lane, t0 < NT ? t0 : 0u);
-    const chunk k1 = load_chunk(lane, t1 < NT ? t1 : 0u);
+    chunk k1 = k0;  // (the same ranks: only the candidate's frequencies differ)
+    if (t1 < NT) k1.s = srank[srank_chunk(NSP, NT, b, lane, t1)];
     if (B->status) {  // (k_sort_entropy: alphabet above the hint -- violation already raised)
         if (tid == 0) B->prelude_bytes = 0;
         return;
@@ -356,14 +354,14 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     if (t0 < NT) {
         if (lane < nchunks) w0 = xh_chunk(k0, lane);
         for (u32 c = lane + 64u; c < nchunks; c += 64u) w0 = w0 + xh_chunk(load_chunk(c, t0), c);
-        for (int o = 32; o > 0; o >>= 1) w0 = w0 + __shfl_xor(w0, o);
-        if (lane == 0) wsum[t0] = w0;
+        w0 = wave_sum(w0);
+        if (lane == 0) wsum[t0] = (double)(m0 + t0) - w0 / nd;  // XH of candidate t0 (one division per wave, not per thread and candidate)
     }
     if (t1 < NT) {
         if (lane < nchunks) w1 = xh_chunk(k1, lane);
         for (u32 c = lane + 64u; c < nchunks; c += 64u) w1 = w1 + xh_chunk(load_chunk(c, t1), c);
-        for (int o = 32; o > 0; o >>= 1) w1 = w1 + __shfl_xor(w1, o);
-        if (lane == 0) wsum[t1] = w1;
+        w1 = wave_sum(w1);
+        if (lane == 0) wsum[t1] = (double)(m0 + t1) - w1 / nd;
     }
     STAMP(3);
     __syncthreads();
@@ -379,7 +377,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             chosen = prev;
             continue;
         }
-        const double XH = (double)(m0 + t) - wsum[t] / nd;
+        const double XH = wsum[t];
         const double d = XH - thr;
         if ((d < 0 ? -d : d) <= guard * thr || !(thr > 0.0)) unsure = true;  // (H == 0: one-symbol block, exact path)
         else if (XH < thr) chosen = (int)t;  // ans_util.hpp:149
@@ -445,7 +443,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     __syncthreads();  // frq (= bits) has been read by everyone; inc[] is complete
     STAMP(9);
 #ifndef FIN_NO_PRELUDE
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);
+    prelude_emit<IPT, false, true>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (logM <= 16)
 #endif
     STAMP(10);
 }

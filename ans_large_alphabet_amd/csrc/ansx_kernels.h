@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     const u32 hwords = sum_here ? 4 * cstride : NSP;
     for (u32 s = tid; s < hwords; s += 256) lds_hist[s] = 0;
     u32* const aux = lds_hist + hwords;  // terms (f64, 8-byte aligned: hwords is even), then the max word
-    if (sum_here && tid < 17) aux[2 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
+    if (sum_here && !tree_sum && tid < 17) aux[2 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
     u32* const my_hist = lds_hist + (tid & 3) * cstride;
     __syncthreads();
     const ansx_map mp = g.map;
@@ -213,21 +213,22 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         double* lds_term = (double*)aux;
         double* ht = (sum_here || tree_sum) ? nullptr : hterm + (u64)b * NSP;
         double part = 0.0;
+        auto term = [&](u32 fr) -> double {
+            if (!fr) return 0.0;
+            const double p = ansx_div_int31((double)fr, nd);
+            return p * ansx_log2_portable(p);
+        };
         for (u32 s = tid; s < NSP; s += 256) {
             u32 fr = lds_hist[s];
             if (sum_here) fr += lds_hist[cstride + s] + lds_hist[2 * cstride + s] + lds_hist[3 * cstride + s];
             h[s] = fr;
-            double t = 0.0;
-            if (fr) {
-                const double p = ansx_div_int31((double)fr, nd);
-                t = p * ansx_log2_portable(p);
-            }
+            const double t = term(fr);
             if (tree_sum) part = part + t;
             else if (sum_here) lds_term[s] = t;
             else ht[s] = t;
         }
         if (tree_sum) {
-            for (int o = 32; o > 0; o >>= 1) part = part + __shfl_xor(part, o);
+            part = wave_sum(part);
             __syncthreads();  // every histogram word has been read: the first 4 doubles of the LDS are free
             double* wpart = (double*)lds_hist;
             if ((tid & 63) == 0) wpart[tid >> 6] = part;
@@ -239,11 +240,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
             }
         } else if (sum_here) {
             // symbols above the block's largest one are absent (+0.0 terms): stop there
-            u32 wmax = lmax;
-            for (int o = 32; o > 0; o >>= 1) {
-                const u32 t = __shfl_xor(wmax, o);
-                wmax = t > wmax ? t : wmax;
-            }
+            const u32 wmax = wave_max(lmax);
             if ((tid & 63) == 0) atomicMax(&aux[2 * NSP + 16], wmax);  // word after the padded terms
             __syncthreads();
             if (tid == 0) {
@@ -272,11 +269,8 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
             if (v) atomicAdd(&h[s], v);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        u32 t = __shfl_xor(lmax, o);
-        lmax = t > lmax ? t : lmax;
-        bad |= __shfl_xor(bad, o);
-    }
+    lmax = wave_max(lmax);
+    bad = wave_or(bad);
     if ((tid & 63) == 0) {
         atomicMax(&blk[b].max_sym, lmax);
         if (bad) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
@@ -370,10 +364,8 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        sigma += __shfl_xor(sigma, o);
-        total += __shfl_xor(total, o);
-    }
+    sigma = wave_sum(sigma);
+    total = wave_sum(total);
     wave_lds_sync();
     // pass 2: exclusive scan of the bins -> first output position of every frequency value
     u32 nsmall, small_mass = 0;
@@ -385,17 +377,9 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
             loc += t;
             locw += t * (lane * per + i);
         }
-        u32 incl = loc, inclw = locw;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            u32 t = __shfl_up(incl, d), tw = __shfl_up(inclw, d);
-            if ((int)lane >= d) {
-                incl += t;
-                inclw += tw;
-            }
-        }
-        nsmall = __shfl(incl, 63);
-        small_mass = __shfl(inclw, 63);  // sum of all frequencies below ANSX_VMAX
+        const u32 incl = wave_incl_scan(loc), inclw = wave_incl_scan(locw);
+        nsmall = wave_last(incl);
+        small_mass = wave_last(inclw);  // sum of all frequencies below ANSX_VMAX
         u32 run = incl - loc, runw = inclw - locw;
         for (u32 i = 0; i < per; i++) {
             const u32 v = lane * per + i;
@@ -882,12 +866,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             sv = s < ns ? chosen_freq(s) : 0u;
         }
         const u32 fr = hv ? sv : 0u;
-        u32 incl = fr;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            u32 t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
-        }
+        const u32 incl = wave_incl_scan(fr);
         const u32 base = carry + incl - fr;
         if (s < ns) {
             if (write16) {
@@ -899,7 +878,7 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             }
             t32[s] = (base << 16) | fr;  // valid while M <= 65536 (base < 2^16, freq < 65535)
         }
-        carry += __shfl(incl, 63);
+        carry += wave_last(incl);
     }
     if (lane == 0) {
         u32 logM = B->m0_log2 + (u32)chosen;
@@ -952,23 +931,13 @@ struct ansx_code {
 // wsum: NT/64 + 1 words of LDS scratch.  Contains two barriers.
 template <typename T> __device__ __forceinline__ T block_excl_scan(T v, T* wsum, u32 tid, u32 nt, T* total)
 {
-    T incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const T t = __shfl_up(incl, d);
-        if ((int)(tid & 63) >= d) incl += t;
-    }
+    const T incl = wave_incl_scan(v);
     const u32 nw = nt >> 6;
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
     if (tid < 64) {
         const T w = tid < nw ? wsum[tid] : (T)0;
-        T wi = w;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {  // nw <= 16
-            const T t = __shfl_up(wi, d);
-            if ((int)tid >= d) wi += t;
-        }
+        const T wi = wave_incl_scan(w);  // nw <= 16: the first row would do
         if (tid < nw) wsum[tid] = wi - w;
         if (tid == nw - 1) wsum[nw] = wi;
     }
@@ -1013,7 +982,10 @@ __global__ __launch_bounds__(256) void k_build_interp_geo(u32 max_ns, uint2* __r
     }
 }
 
-__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, u64 u, u32 i,
+// W: the arithmetic type -- u64 in general; u32 where the universe is below 2^31 (frames up to 2^30: every quantity
+// below is at most 2 u), half the instructions on a machine without 64-bit integer VALU operations.
+template <typename W = u64>
+__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, W u, u32 i,
     const uint2* __restrict__ geo_row = nullptr)
 {
     u32 a, n, rank;
@@ -1025,12 +997,13 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
         a = nd.a, n = nd.n, rank = nd.rank;
     }
     const u32 h = (n + 1) >> 1, mid = i;
-    const u64 n1 = h - 1, n2 = n - h;
-    const u64 low = (a == 0) ? 1ull : (u64)inc[a - 1] + 2ull;          // parent v + 1
-    const u64 high = (a + n == ns) ? (u + 1ull) : (u64)inc[a + n];     // parent v - 1
-    const u64 v = (u64)inc[mid] + 1ull;                                // interp.hpp:73
-    u64 val = v - low - n1 + 1ull;
-    const u64 U = high - n2 - low - n1 + 1ull;
+    const W one = 1;
+    const W n1 = h - 1, n2 = n - h;
+    const W low = (a == 0) ? one : (W)inc[a - 1] + 2;          // parent v + 1
+    const W high = (a + n == ns) ? (u + one) : (W)inc[a + n];  // parent v - 1
+    const W v = (W)inc[mid] + one;                             // interp.hpp:73
+    W val = v - low - n1 + one;
+    const W U = high - n2 - low - n1 + one;
     ansx_code c;
     c.rank = rank;
     if (U == 1) {  // interp.hpp:31-32
@@ -1038,17 +1011,19 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
         c.len = 0;
         return c;
     }
-    const u32 bb = 64 - __clzll((unsigned long long)(U - 1));  // hi(U-1)+1
-    const u64 d = 2ull * U - (1ull << bb);
+    u32 bb;  // hi(U-1)+1
+    if constexpr (sizeof(W) == 8) bb = 64 - __clzll((unsigned long long)(U - 1));
+    else bb = 32 - __clz((u32)(U - 1));
+    const W d = 2 * U - (one << bb);
     val = val + (U - (d >> 1));
     if (val > U) val -= U;
-    const u64 m = (1ull << bb) - U;
+    const W m = (one << bb) - U;
     if (val <= m) {
-        c.code = (u32)(val - 1ull);
+        c.code = (u32)(val - one);
         c.len = bb - 1;
     } else {
         val += m;
-        c.code = (u32)(((val - 1ull) >> 1) | (((val - 1ull) & 1ull) << (bb - 1)));
+        c.code = (u32)(((val - one) >> 1) | (((val - one) & one) << (bb - 1)));
         c.len = bb;
     }
     return c;
@@ -1063,14 +1038,16 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
 //               written behind the block's B->pre_bytes.
 // PA == true:  the alphabet header of per-block compaction (pseudo_adaptive.cpp:106-113): u32 ns, u32 `uni`,
 //               code of the ns running sums over universe `uni`; sets B->pre_bytes.
-template <int IPT, bool PA = false>
+// W32: the caller guarantees a universe below 2^31 (32-bit code arithmetic, see interp_item).
+template <int IPT, bool PA = false, bool W32 = false>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
     u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
     u64 uni = 0, u32* __restrict__ hints = nullptr, const uint2* __restrict__ geo = nullptr)
 {
     const uint2* const geo_row = (geo != nullptr && ns >= 1) ? geo + interp_geo_row(ns) : nullptr;  // (tabulated tree nodes)
     constexpr bool SMALL = IPT > 0;
-    const u64 u = PA ? uni : ((u64)1 << logM) + ns + 1;  // ans_util.hpp:60
+    typedef typename std::conditional<W32, u32, u64>::type W;
+    const W u = (W)(PA ? uni : ((u64)1 << logM) + ns + 1);  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
     if (SMALL) {
 #pragma unroll
@@ -1078,13 +1055,13 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
             const u32 i = tid + 256 * j;
             mine[j].len = 0;
             if (i < ns) {
-                mine[j] = interp_item(inc, ns, u, i, geo_row);
+                mine[j] = interp_item<W>(inc, ns, u, i, geo_row);
                 off[mine[j].rank] = mine[j].len;
             }
         }
     } else {
         for (u32 i = tid; i < ns; i += 256) {
-            ansx_code c = interp_item(inc, ns, u, i, geo_row);
+            ansx_code c = interp_item<W>(inc, ns, u, i, geo_row);
             off[c.rank] = c.len;
         }
     }
@@ -1143,7 +1120,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
-        for (u32 i = tid; i < ns; i += 256) place(interp_item(inc, ns, u, i, geo_row));
+        for (u32 i = tid; i < ns; i += 256) place(interp_item<W>(inc, ns, u, i, geo_row));
     }
     __syncthreads();
     const u32 nbytes = nwords * 4;
@@ -1185,7 +1162,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         out[q] = (u8)logM;
     }
     p += vb + 1;
-    for (u32 j = tid; j < nbytes; j += 256) out[p + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
+    for (u32 w = tid; w < nwords; w += 256) st_u32_unaligned(out + p + 4 * w, bits[w]);  // (any byte alignment)
     if (tid == 0) {
         B->hdr_bytes = hdr;
         B->prelude_bytes = p + nbytes;
@@ -2067,11 +2044,10 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(ansx_geo g, const ansx_blk*
     const u32 lo = wave * per < NB ? wave * per : NB, hi = (lo + per) < NB ? (lo + per) : NB;
     u64 sum = 0;
     for (u32 i = lo + lane; i < hi; i += 64) sum += blk[i].stream_bytes;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);  // the wave's total in every lane
+    sum = wave_sum(sum);  // the wave's total in every lane
     u64 total;
     u64 run = block_excl_scan<u64>(lane == 63 ? sum : 0ull, part, tid, 1024, &total);  // bytes before this wave's range
-    run = __shfl(run, 63);
+    run = wave_last(run);
     if (tid == 0) {
         block_off[NB] = total;
         result[0] = total;  // payload bytes
@@ -2080,14 +2056,9 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(ansx_geo g, const ansx_blk*
     for (u32 i0 = lo; i0 < hi; i0 += 64) {
         const u32 i = i0 + lane;
         const u64 v = i < hi ? (u64)blk[i].stream_bytes : 0ull;
-        u64 incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u64 t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
-        }
+        const u64 incl = wave_incl_scan(v);
         if (i < hi) block_off[i] = run + incl - v;
-        run += __shfl(incl, 63);
+        run += wave_last(incl);
     }
 }
 
@@ -3319,12 +3290,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         u32 loc = 0;
         for (u32 i = 0; i < per; i++)
             if (lo + i < W) loc += (u32)__builtin_popcount(bwp[lo + i].x);
-        u32 incl = loc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(incl, d);
-            if ((int)tid >= d) incl += t;
-        }
+        const u32 incl = wave_incl_scan(loc);
         dec_lut_rank bl;
         bl.ep = ep;
         u32 run = incl - loc + bl.bias();

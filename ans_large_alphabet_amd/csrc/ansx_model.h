@@ -160,11 +160,8 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
             done = nvec << 2;
         }
         for (u32 i = done + tid; i < nb; i += 256) take(src[i]);
-        for (int o = 32; o > 0; o >>= 1) {
-            const u32 t = __shfl_xor(lmax, o), t2 = __shfl_xor(xmax, o);
-            lmax = t > lmax ? t : lmax;
-            xmax = t2 > xmax ? t2 : xmax;
-        }
+        lmax = wave_max(lmax);
+        xmax = wave_max(xmax);
         if (lane == 0) {
             atomicMax(&sh_u[0], lmax);
             atomicMax(&sh_u[3], xmax);
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
             hterm[s] = t;
             hcopy[s] = fr;  // (only this thread touches column s)
         }
-        for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o);
+        nz = wave_sum(nz);
         if (lane == 0) atomicAdd(&sh_u[1], nz);
     }
     __syncthreads();
@@ -263,13 +260,8 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
             const u32 per = ANSX_MS_VMAX / 64;
             u32 loc = 0;
             for (u32 i = 0; i < per; i++) loc += cnt[lane * per + i];
-            u32 incl = loc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 t = __shfl_up(incl, d);
-                if ((int)lane >= d) incl += t;
-            }
-            nsmall = __shfl(incl, 63);
+            const u32 incl = wave_incl_scan(loc);
+            nsmall = wave_last(incl);
             u32 run = incl - loc;
             for (u32 i = 0; i < per; i++) {
                 const u32 t = cnt[lane * per + i];

@@ -253,11 +253,8 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         if (tid + q * nt < nb) insert_one(vals[q]);
     for (u32 i = tid + RF_VPT * nt; i < nb; i += nt) insert_one(src[i]);  // (fewer than 1024 threads)
     // (one atomic per wave: 1024 threads on the same two words queue up in the LDS unit)
-    for (int o = 32; o > 0; o >>= 1) {
-        const u32 om = (u32)__shfl_xor((int)lmax, o);
-        lmax = om > lmax ? om : lmax;
-        ldistinct += (u32)__shfl_xor((int)ldistinct, o);
-    }
+    lmax = wave_max(lmax);
+    ldistinct = wave_sum(ldistinct);
     if ((tid & 63u) == 0) {
         atomicMax(&sh_max, lmax);
         atomicAdd(&sh_cnt, ldistinct);
@@ -305,12 +302,7 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
                 if (descending) bin = nbins - 1 - bin;
                 loc += (tid * per + i < nbins) ? hist[bin] : 0u;
             }
-            u32 incl = loc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                u32 t = __shfl_up(incl, d);
-                if ((int)tid >= d) incl += t;
-            }
+            const u32 incl = wave_incl_scan(loc);
             const u32 excl = incl - loc;
             if (excl < target && incl >= target) {  // exactly one lane
                 u32 run = excl, found = 0, bef = excl;
@@ -337,11 +329,6 @@ __device__ __forceinline__ void rfold_remap_hash_body(const u32* __restrict__ in
         __syncthreads();
         for (u32 i = tid; i < nbins; i += nt) hist[i] = 0;
         __syncthreads();
-    };
-    auto wave_sum = [&](u32 v) -> u32 {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-        return v;
     };
     u32 before;
     // ---- c*

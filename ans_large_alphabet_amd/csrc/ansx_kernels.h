@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
 // Entropy: p*log2(p) terms lane-parallel, summed serially in index order so that the rounding
 // matches a scalar left-to-right accumulation.
 // ------------------------------------------------------------------------------------------
-#define ANSX_VMAX 512u
-#define ANSX_MASKV 512u
+#define ANSX_VMAX 256u
+#define ANSX_MASKV 256u
 
 // Single-wave workgroups: LDS operations of one wave execute in order, so a "barrier" only has
 // to stop the compiler from reordering and wait for the LDS queue; __syncthreads() would also

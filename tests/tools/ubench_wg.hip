@@ -23,7 +23,9 @@ int main()
     hipEventCreate(&e1);
     const int grids[] = { 512, 4096, 16384 };
     const int thr[] = { 256, 1024 };
-    const size_t ldsb[] = { 4096, 40 * 1024, 78 * 1024, 100 * 1024 };
+    const size_t ldsb[] = { 4096, 16 * 1024, 40 * 1024, 78 * 1024 };
+    const unsigned spins[] = { 0, 5, 15 };
+    for (unsigned us : spins)
     for (int t : thr)
         for (size_t l : ldsb) {
             hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
@@ -31,7 +33,7 @@ int main()
                 float best = 1e9f;
                 for (int r = 0; r < 3; r++) {
                     hipEventRecord(e0);
-                    hipLaunchKernelGGL(k_spin, dim3(g), dim3(t), l, 0, 17u, d);
+                    hipLaunchKernelGGL(k_spin, dim3(g), dim3(t), l, 0, us, d);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
@@ -39,7 +41,7 @@ int main()
                     best = ms < best ? ms : best;
                 }
                 const double per_cu = 160.0 * 1024 / (double)l;
-                printf("threads %4d lds %6zu B grid %5d: %.3f ms  (WGs/CU by LDS %.1f, by threads %d)\n", t, l, g, best, per_cu, 2048 / t);
+                printf("spin %2u us threads %4d lds %6zu B grid %5d: %.3f ms  (WGs/CU by LDS %.1f, by threads %d)\n", us, t, l, g, best, per_cu, 2048 / t);
             }
         }
     return 0;

@@ -177,6 +177,27 @@ class ANSint(_Codec):
 
 # ---------------------------------------------------------------- container parsing (host)
 
+def unpack_restart_points(raw):
+    """29-byte restart points -> (cursors u32[n], states u64[n * 4]): states 0, 1 as one 104-bit little-endian
+    integer in bytes 0..12, states 2, 3 in bytes 13..25 (52 bits each), the cursor in bytes 26..28."""
+    rec = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1, 29).astype(np.uint64)
+    n = rec.shape[0]
+    st = np.zeros((n, 4), dtype=np.uint64)
+    m52 = np.uint64((1 << 52) - 1)
+    for pair in range(2):
+        b = rec[:, 13 * pair: 13 * pair + 13]
+        lo = np.zeros(n, dtype=np.uint64)
+        for i in range(8):
+            lo |= b[:, i] << np.uint64(8 * i)
+        hi = np.zeros(n, dtype=np.uint64)
+        for i in range(5):
+            hi |= b[:, 8 + i] << np.uint64(8 * i)
+        st[:, 2 * pair] = lo & m52
+        st[:, 2 * pair + 1] = (lo >> np.uint64(52)) | (hi << np.uint64(12))
+    off = (rec[:, 26] | (rec[:, 27] << np.uint64(8)) | (rec[:, 28] << np.uint64(16))).astype(np.uint32)
+    return off, st.reshape(-1)
+
+
 def parse_container(buf):
     """Split a container (np.uint8) into header fields, per-block streams and restart points."""
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
@@ -189,10 +210,14 @@ def parse_container(buf):
     boff = np.frombuffer(buf[idx_off: idx_off + 8 * (nb + 1)].tobytes(), dtype=np.uint64)
     ck_off_off = idx_off + 8 * (nb + 1)
     nck = nb * H.ckpts_per_block
-    ck_off = np.frombuffer(buf[ck_off_off: ck_off_off + 4 * nck].tobytes(), dtype=np.uint32)
-    ck_state_off = (ck_off_off + 4 * nck + 7) // 8 * 8
-    ck_state = np.frombuffer(buf[ck_state_off: ck_state_off + 32 * nck].tobytes(), dtype=np.uint64)
-    hint_off = (ck_state_off + 32 * nck + 15) // 16 * 16
+    if H.kind & 0x200:  # wide restart points: u32 cursors, then 4 x u64 states (the v2 form)
+        ck_off = np.frombuffer(buf[ck_off_off: ck_off_off + 4 * nck].tobytes(), dtype=np.uint32)
+        ck_state_off = (ck_off_off + 4 * nck + 7) // 8 * 8
+        ck_state = np.frombuffer(buf[ck_state_off: ck_state_off + 32 * nck].tobytes(), dtype=np.uint64)
+        hint_off = (ck_state_off + 32 * nck + 15) // 16 * 16
+    else:  # packed 29-byte records
+        ck_off, ck_state = unpack_restart_points(buf[ck_off_off: ck_off_off + 29 * nck])
+        hint_off = (ck_off_off + 29 * nck + 15) // 16 * 16
     hints = np.frombuffer(buf[hint_off: hint_off + 32 * nb].tobytes(), dtype=np.uint32).reshape(nb, 8)
     p0 = int(H.payload_offset)
     streams = [buf[p0 + int(boff[i]): p0 + int(boff[i + 1])] for i in range(nb)]

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -36,7 +37,7 @@ struct ProfRec {
     hipEvent_t e0, e1;
 };
 
-struct Layout {  // container layout, a pure function of the geometry
+struct Layout {  // container layout, a pure function of the geometry (restart-point format included)
     u64 index_off, ckoff_off, ckstate_off, hint_off, payload_off;
 };
 
@@ -62,6 +63,7 @@ struct ansx_ctx {
     // on it without waiting for the header to come back, and a one-thread kernel compares it with the real one
     std::map<std::array<u64, 4>, ansx_container_header> hdr_cache;
     std::map<u32, DevBuf> geo;   // tree nodes of the interpolative code per alphabet size, tabulated per symbol-array size (<= 4096)
+    std::set<u64> wide_hint;     // geometries that met a frame above 2^16: wide restart points from the start
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
     const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
     const u32* cur_src = nullptr;    // set by encode_general: the ints the model kernels saw (the input, or its remapped form)
@@ -85,6 +87,8 @@ struct ansx_ctx {
         u32 parse_stage_words = 0;    // ANSX_PARSE_STAGE_WORDS: 0 = default
         bool model_fused = false;     // ANSX_MODEL_FUSED: the single LDS-resident model kernel instead of the five tailored ones
         bool model_sync = false;      // ANSX_MODEL_SYNC: always discover the alphabet with the mid-call read-back
+        u32 wide_at = 16;             // ANSX_TEST_WIDE_AT: frames above 2^this need wide restart points (tests lower it to force the repeat)
+        bool wide_restart = false;    // ANSX_WIDE_RESTART: 36-byte restart points (the v2 form) in every container
         u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
         u32 t_hint = 0;               // ANSX_T_HINT: candidates per block for every call (0 = learn per geometry)
         bool no_fast_model = false;   // ANSX_NO_FAST_MODEL: optimistic calls keep the exact model kernels
@@ -172,6 +176,24 @@ struct Plan {
     u32 NSP;
 };
 
+Layout layout_of(const ansx_geo& g, bool plain)
+{
+    Layout L;
+    const u64 nck = (u64)g.nblocks * g.nckf;
+    L.index_off = sizeof(ansx_container_header);
+    L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
+    if (g.ckw) {
+        L.ckstate_off = rup(L.ckoff_off + 4 * nck, 8);
+        L.hint_off = rup(L.ckstate_off + 32 * nck, 16);  // 8 x u32 parse hints per block
+    } else {
+        L.ckstate_off = L.ckoff_off;  // (one array of records)
+        L.hint_off = rup(L.ckoff_off + (u64)ANSX_CK_RECORD * nck, 16);
+    }
+    L.payload_off = L.hint_off + 32 * (u64)g.nblocks;
+    if (plain) L.index_off = L.ckoff_off = L.ckstate_off = L.hint_off = L.payload_off = 0;
+    return L;
+}
+
 int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
 {
     if (kind != ANSX_FOLD && kind != ANSX_RFOLD && kind != ANSX_MSB && kind != ANSX_INT) return ANSX_ERR_ARG;
@@ -220,20 +242,23 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     g.f = (u32)f;
     g.kind = (u32)kind;
     g.pa = pa ? 1u : 0u;
+    g.ckw = 0;            // packed restart points unless set_restart_format() says otherwise
     g.payload_bytes = 0;  // (set by decode_dev from the container header)
     g.map = kind == ANSX_MSB ? map_msb() : (kind == ANSX_INT ? map_int() : map_fold((u32)f));
     P->g = g;
     // symbol-array stride: the reference's MAX_SIGMA (ans_fold.hpp:70; ans_msb.hpp:28 has 1280)
     P->NSP = (u32)codec_nsp(kind, (u32)f);
-    Layout L;
-    L.index_off = sizeof(ansx_container_header);
-    L.ckoff_off = L.index_off + 8 * ((u64)g.nblocks + 1);
-    L.ckstate_off = rup(L.ckoff_off + 4 * (u64)g.nblocks * g.nckf, 8);
-    L.hint_off = rup(L.ckstate_off + 32 * (u64)g.nblocks * g.nckf, 16);  // 8 x u32 parse hints per block
-    L.payload_off = L.hint_off + 32 * (u64)g.nblocks;
-    if (P->plain) L.index_off = L.ckoff_off = L.ckstate_off = L.hint_off = L.payload_off = 0;
-    P->lay = L;
+    P->lay = layout_of(g, P->plain);
     return ANSX_OK;
+}
+
+// Restart points: packed 29-byte records (container v3 default) or the wide form (ansx_dev.h).  Wide is needed when a
+// state can exceed 52 bits (frames above 2^16: ANSint always may, the others only with large alphabets in large
+// blocks) or a cursor 24 bits; the encoder finds out about frames on the device and repeats the call (encode_dev).
+void set_restart_format(Plan* P, bool wide)
+{
+    P->g.ckw = wide ? 1u : 0u;
+    P->lay = layout_of(P->g, P->plain);
 }
 
 // fold maps have power-of-two thresholds 2^(f+7), 2^(f+15), 2^(f+23): the encoder derives the exception-byte
@@ -333,6 +358,7 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
 
 // --------------------------------------------------------------------------------- encode
 constexpr int ANSX_RETRY_GENERAL = -1;  // internal: an optimistic assumption did not hold, repeat without it
+constexpr int ANSX_RETRY_WIDE = -2;     // internal: a frame above 2^16 in a call laid out for packed restart points, repeat with wide ones
 
 // ns_cap == 0: discovery mode -- the largest alphabet / frame of the call are read back between the
 // model kernels and the encoder launch (one host round trip per candidate batch).
@@ -566,6 +592,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         max_ns = c->h_pin[ANSX_G_MAXNSYMS];
         if (c->h_pin[ANSX_G_PAD] == 0) break;
     }
+    if (!P.plain && !g.ckw && g.nckf != 0 && max_logM > c->dbg.wide_at) return ANSX_RETRY_WIDE;  // (discovery path: known before anything is encoded)
     if (!always16 && (max_logM > 16 || test_fixup))  // mixed call: a frame above 2^16 sends every block to the integer-state encoder
         LAUNCH(c, "k_table16_from32", k_table16_from32, NB, 256, 0, s, g, NSP, (const ansx_blk*)blk,
             (const u32*)c->tab32.p, (ansx_enc_entry*)c->table.p);
@@ -655,6 +682,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         if (c->h_pin[ANSX_G_ERR] & (1u << ANSX_G_VIOL_BIT)) return ANSX_RETRY_GENERAL;  // (rfold: optimistic hash table too small)
         if (c->h_pin[ANSX_G_PAD] != 0 || c->h_pin[ANSX_G_MAXLOGM] > 16 || c->h_pin[ANSX_G_MAXNSYMS] > ns_cap)
             return ANSX_RETRY_GENERAL;
+        if (!g.ckw && g.nckf != 0 && c->h_pin[ANSX_G_MAXLOGM] > c->dbg.wide_at) return ANSX_RETRY_GENERAL;  // (tests only: wide_at < 16)
     }
     int st = flags_to_status(c->h_pin[ANSX_G_ERR]);
     if (st) return st;
@@ -960,7 +988,7 @@ int resolve_near(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t 
     return rc;
 }
 
-int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes,
+int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes,
     hipStream_t s)
 {
     // The first call of a geometry discovers its alphabet size with a mid-call read-back; later calls
@@ -1000,10 +1028,12 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
+    if (rc == ANSX_RETRY_WIDE) return rc;
     // close calls of the stop rule (counted by the exact kernels only; the fast path repeats on them): the host decides
     u32 redecided = 0;
     const u32 near_blocks = c->h_pin[ANSX_G_NEAR];  // (a forced repeat skips the rule for the blocks it forces)
     if (rc == ANSX_OK && near_blocks != 0) rc = resolve_near(c, P, d_in, d_out, cap, out_bytes, s, &seen, &redecided);
+    if (rc == ANSX_RETRY_WIDE) return rc;
     c->last.host_redecided = redecided;
     c->last.path = path;
     c->last.max_nsyms = c->h_pin[ANSX_G_MAXNSYMS];
@@ -1026,6 +1056,27 @@ int encode_dev(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t ca
         }
     }
     return rc;
+}
+
+// Restart-point format of the call (see set_restart_format): packed unless the geometry rules it out or an earlier
+// call of the geometry met a frame above 2^16; a call that meets one is repeated once with the wide form.
+int encode_dev(ansx_ctx* c, const Plan& P0, const u32* d_in, u8* d_out, size_t cap, size_t* out_bytes, hipStream_t s)
+{
+    Plan P = P0;
+    if (!P.plain) {
+        const u64 key = ((u64)P.g.pa << 48) | ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
+        const size_t stream_bound = block_bound(P.g.kind, P.g.f, P.g.block_ints, P.g.pa != 0) + 16;
+        const bool must = P.g.kind == ANSX_INT || stream_bound >= ((size_t)1 << ANSX_CK_CURSOR_BITS) || c->dbg.wide_restart;
+        set_restart_format(&P, must || c->wide_hint.count(key) != 0);
+        int rc = encode_dev_once(c, P, d_in, d_out, cap, out_bytes, s);
+        if (rc != ANSX_RETRY_WIDE) return rc;
+        c->wide_hint.insert(key);
+        set_restart_format(&P, true);
+        const int rc2 = encode_dev_once(c, P, d_in, d_out, cap, out_bytes, s);
+        c->last.path |= 32u;  // repeated with wide restart points
+        return rc2;
+    }
+    return encode_dev_once(c, P, d_in, d_out, cap, out_bytes, s);
 }
 
 // --------------------------------------------------------------------------------- decode
@@ -1211,10 +1262,10 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     if (bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
     ansx_container_header H;
     memcpy(&H, h, sizeof(H));
-    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
+    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
     if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
-    const u32 k = H.kind & 0xFFu;  // bit 8: per-block alphabet compaction
-    if ((H.kind & ~0x1FFu) || k > 3 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
+    const u32 k = H.kind & 0xFFu;  // bit 8: per-block alphabet compaction, bit 9: wide restart points
+    if ((H.kind & ~0x3FFu) || k > 3 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
     if ((k == ANSX_MSB || k == ANSX_INT) ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > ANSX_MAX_FIDELITY)) return ANSX_ERR_FORMAT;
     *out = H;
     return ANSX_OK;
@@ -1311,6 +1362,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         o.reserved = 0;
         if (H.block_ints == ANSX_SINGLE_STREAM) return ANSX_ERR_FORMAT;
         if ((rc = make_plan((int)(H.kind & 0xFFu), (int)f, (size_t)H.n, &o, &P))) return ANSX_ERR_FORMAT;
+        set_restart_format(&P, (H.kind & ANSX_KIND_WIDE_RESTART) != 0);
         if (P.g.nblocks != H.nblocks || P.g.nckf != H.ckpts_per_block || P.g.ckpt != H.ckpt_interval
             || P.lay.payload_off != H.payload_offset)
             return ANSX_ERR_FORMAT;
@@ -1445,7 +1497,7 @@ int ansx_init(int device, ansx_ctx** out)
         return ANSX_ERR_HIP;
     }
     static const char* const names[] = { "ANSX_TEST_TABLE16_FIXUP", "ANSX_ENCODE_GTAB16", "ANSX_PARSE_GENERIC", "ANSX_PARSE_WIN", "ANSX_PARSE_FAST",
-        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD", "ANSX_CAND_CHAINS", "ANSX_NEAR_BAND", "ANSX_TEST_NEAR_FLIP" };
+        "ANSX_DECODE_TABLE", "ANSX_NO_STREAM_LDS", "ANSX_DECODE_MODE", "ANSX_PARSE_STAGE_WORDS", "ANSX_MODEL_FUSED", "ANSX_MODEL_SYNC", "ANSX_NS_HINT", "ANSX_T_HINT", "ANSX_NO_FAST_MODEL", "ANSX_FAST_GUARD", "ANSX_CAND_CHAINS", "ANSX_NEAR_BAND", "ANSX_TEST_NEAR_FLIP", "ANSX_WIDE_RESTART", "ANSX_TEST_WIDE_AT" };
     for (const char* nm : names)
         if (const char* v = getenv(nm)) (void)ansx_debug_set(c, nm, v);
     *out = c;
@@ -1518,6 +1570,12 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NS_HINT")) c->dbg.ns_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
+    else if (!strcmp(name, "ANSX_WIDE_RESTART")) c->dbg.wide_restart = on;
+    else if (!strcmp(name, "ANSX_TEST_WIDE_AT")) {
+        const u32 v = (value && value[0]) ? (u32)strtoul(value, nullptr, 10) : 16u;
+        if (v > 16) return ANSX_ERR_ARG;
+        c->dbg.wide_at = v;
+    }
     else if (!strcmp(name, "ANSX_NEAR_BAND")) c->dbg.near_band = (value && value[0]) ? strtod(value, nullptr) : ANSX_NEAR_BAND;
     else if (!strcmp(name, "ANSX_TEST_NEAR_FLIP")) c->dbg.near_flip = on;
     else if (!strcmp(name, "ANSX_CAND_CHAINS")) {
@@ -1578,6 +1636,7 @@ size_t ansx_bound(int kind, int f, size_t n, const ansx_opts* opts)
 {
     Plan P;
     if (make_plan(kind, f, n, opts, &P)) return 0;
+    if (!P.plain) set_restart_format(&P, true);  // (the larger of the two index forms)
     size_t per = block_bound(kind, (u32)f, 0, false);
     return (size_t)P.lay.payload_off + (size_t)P.g.nblocks * per + (P.g.pa ? 11 : 7) * n + 64;
 }
@@ -1692,6 +1751,7 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
                 (h.kind & 0x100u) ? (u32)ANSX_FLAG_COMPACT_ALPHABET : 0u, 0 };
             Plan PP;
             if (make_plan((int)(h.kind & 0xFFu), (int)h.fidelity, (size_t)h.n, &po, &PP)) return ANSX_ERR_FORMAT;
+            set_restart_format(&PP, (h.kind & ANSX_KIND_WIDE_RESTART) != 0);
             if (PP.g.nblocks != h.nblocks || PP.g.nckf != h.ckpts_per_block || PP.lay.payload_off != h.payload_offset) return ANSX_ERR_FORMAT;
         }
         D.part[i].src = d_parts[i];
@@ -1712,11 +1772,15 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
         (H[0].kind & 0x100u) ? (u32)ANSX_FLAG_COMPACT_ALPHABET : 0u, 0 };
     Plan P;
     if (make_plan((int)(H[0].kind & 0xFFu), (int)H[0].fidelity, (size_t)n, &o, &P)) return ANSX_ERR_FORMAT;
+    // (bit 9: the restart-point format.  The parts agree on it -- their kind words are equal -- and the result keeps it;
+    // a part that needed wide restart points next to parts that did not is refused: re-encode those with ANSX_WIDE_RESTART)
+    set_restart_format(&P, (H[0].kind & ANSX_KIND_WIDE_RESTART) != 0);
     if (P.g.nblocks != nblocks || P.g.nckf != H[0].ckpts_per_block) return ANSX_ERR_FORMAT;
     const u64 total = P.lay.payload_off + pay;
     if (total > cap) return ANSX_ERR_CAPACITY;
     D.nparts = (u32)nparts;
     D.nckf = P.g.nckf;
+    D.ckw = P.g.ckw;
     D.ckoff_off = P.lay.ckoff_off;
     D.ckstate_off = P.lay.ckstate_off;
     D.hint_off = P.lay.hint_off;
@@ -1737,7 +1801,8 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
     u64 max_pieces = 1;
     for (int i = 0; i < nparts; i++) {
         const u64 nb_ = D.part[i].nblocks;
-        const u64 pieces = (8 * nb_ + 65535) / 65536 + (4 * nb_ * D.nckf + 65535) / 65536 + (32 * nb_ * D.nckf + 65535) / 65536
+        const u64 cko_unit = D.ckw ? 4 : ANSX_CK_RECORD, cks_unit = D.ckw ? 32 : 0;  // (as k_merge_containers walks them)
+        const u64 pieces = (8 * nb_ + 65535) / 65536 + (cko_unit * nb_ * D.nckf + 65535) / 65536 + (cks_unit * nb_ * D.nckf + 65535) / 65536
             + (32 * nb_ + 65535) / 65536 + (D.part[i].payload_bytes + 65535) / 65536;
         max_pieces = std::max(max_pieces, pieces);
     }

@@ -310,9 +310,33 @@ struct ansx_geo {
     u32 f;           // fidelity (0 for ANSmsb)
     u32 kind;        // 0 fold, 1 rfold, 2 msb, 3 int
     u32 pa;          // 1: per-block alphabet compaction (ansx_pa.h)
+    u32 ckw;         // restart points: 0 = packed 29-byte records, 1 = wide (u32 cursor + 4 x u64 states), see below
     ansx_map map;    // value <-> symbol map of this codec
     u64 payload_bytes;  // decode: bytes of block streams behind the container's payload offset (0 on the encode side)
 };
+
+// Restart points in the container index.  A state is below 2^36 M and a cursor below the block's
+// stream length, so with frames up to 2^16 and streams below 16 MiB a restart point is 4 x 52 + 24 bits = 29 bytes
+// (container v3, the default): states 0 and 1 as one 104-bit little-endian integer in bytes 0..12 (state 0 in the low
+// 52 bits), states 2 and 3 likewise in bytes 13..25, the cursor in bytes 26..28.  Anything larger (ANSint frames,
+// huge blocks) keeps the v2 arrays -- u32 cursors, then 4 x u64 states -- and says so in the header (kind | 0x200).
+#define ANSX_CK_RECORD 29u
+#define ANSX_CK_STATE_BITS 52u
+#define ANSX_CK_CURSOR_BITS 24u
+#define ANSX_KIND_WIDE_RESTART 0x200u
+ANSX_D void ckpt_load(const ansx_geo& g, const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u64 idx,
+    u32 j, u64* st, u32* po)
+{
+    if (g.ckw) {
+        *st = ckpt_state[idx * 4 + j];
+        *po = ckpt_off[idx];
+    } else {
+        const u8* rec = (const u8*)ckpt_state + idx * ANSX_CK_RECORD;
+        const u8* p = rec + 13u * (j >> 1) + 6u * (j & 1u);  // (an odd state starts at bit 52 = byte 6, bit 4)
+        *st = (((const ansx_u64_u*)p)->v >> (4u * (j & 1u))) & ((1ull << ANSX_CK_STATE_BITS) - 1ull);
+        *po = ((const ansx_u32_u*)(rec + 25))->v >> 8;
+    }
+}
 
 // One entry pair of a container's block index, as untrusted as the payload: the same conditions k_validate_index
 // applies to the whole index, for the one block a parser is about to touch (a reference stream has at least 2

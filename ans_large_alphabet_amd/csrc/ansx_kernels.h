@@ -1690,8 +1690,27 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
         // ck_seg (the decoder of that segment starts with exactly these states and cursor)
         if (ck_seg && gidx == ck_g) {
             const u64 idx = (u64)b * g.nckf + (ck_seg - 1);
-            ckpt_state[idx * 4 + ql] = tab.state(L);
-            if (ql == 0) ckpt_off[idx] = L.p - pbias;
+            const u64 stv = tab.state(L);
+            if (g.ckw) {
+                ckpt_state[idx * 4 + ql] = stv;
+                if (ql == 0) ckpt_off[idx] = L.p - pbias;
+            } else {
+                // packed record (ansx_dev.h): the even lane of a pair stores both states as one 104-bit integer.  (A frame
+                // above 2^16 would not fit: the host repeats such a call with wide restart points.)
+                u8* rec = (u8*)ckpt_state + idx * ANSX_CK_RECORD;
+                const u64 pst = ((u64)quad_perm<ANSX_QP(1, 0, 3, 2)>((u32)(stv >> 32)) << 32) | quad_perm<ANSX_QP(1, 0, 3, 2)>((u32)stv);
+                if ((ql & 1u) == 0) {
+                    u8* pp = rec + 13u * (ql >> 1);
+                    st_u64_unaligned(pp, (stv & ((1ull << ANSX_CK_STATE_BITS) - 1ull)) | (pst << ANSX_CK_STATE_BITS));
+                    st_u32_unaligned(pp + 8, (u32)(pst >> 12));
+                    pp[12] = (u8)(pst >> 44);
+                }
+                if (ql == 0) {
+                    const u32 cur = L.p - pbias;
+                    st_u16_unaligned(rec + 26, (u16)cur);
+                    rec[28] = (u8)(cur >> 16);
+                }
+            }
             ck_seg--;
             ck_g -= cg;
         }
@@ -2106,10 +2125,10 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // ansx_container_header, little endian (include/ansx.h)
-    const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
+    const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
     for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
     u32* w = (u32*)(out + 8);
-    w[0] = g.kind | (g.pa ? 0x100u : 0u);  // bit 8: per-block alphabet compaction
+    w[0] = g.kind | (g.pa ? 0x100u : 0u) | (g.ckw ? ANSX_KIND_WIDE_RESTART : 0u);  // bit 8: per-block alphabet compaction, bit 9: wide restart points
     w[1] = g.f;
     *(u64*)(out + 16) = g.n;
     w = (u32*)(out + 24);
@@ -2155,10 +2174,10 @@ __global__ __launch_bounds__(256) void k_assemble(ansx_geo g, const u32* __restr
             result[0] = total;  // payload bytes
             if (with_header) {
                 // ansx_container_header, little endian (include/ansx.h)
-                const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '2', 0, 0 };
+                const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
                 for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
                 u32* w = (u32*)(out + 8);
-                w[0] = g.kind | (g.pa ? 0x100u : 0u);  // bit 8: per-block alphabet compaction
+                w[0] = g.kind | (g.pa ? 0x100u : 0u) | (g.ckw ? ANSX_KIND_WIDE_RESTART : 0u);  // bit 8: per-block alphabet compaction, bit 9: wide restart points
                 w[1] = g.f;
                 *(u64*)(out + 16) = g.n;
                 w = (u32*)(out + 24);
@@ -2917,8 +2936,8 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
             p = (int)sbytes - 32;
         } else {
             const u64 idx = (u64)b * g.nckf + (seg - 1);
-            st = ckpt_state[idx * 4 + (3 - ql)];
-            u32 po = ckpt_off[idx];
+            u32 po;
+            ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &st, &po);
             p = (int)(po < sbytes ? po : sbytes);
         }
         u32 q = ANSX_DEC_Q(p);
@@ -3023,8 +3042,8 @@ __device__ __forceinline__ void dec_ring_prefetch(dec_ring_pre& P, const ansx_ge
         P.p = (int)sbytes - 32;
     } else if (seg < nseg) {
         const u64 idx = (u64)b * g.nckf + (seg - 1);
-        P.st = ckpt_state[idx * 4 + (3 - ql)];
-        const u32 po = ckpt_off[idx];
+        u32 po;
+        ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &P.st, &po);
         P.p = (int)(po < sbytes ? po : sbytes);
     }
     P.lo = (P.p - T) & ~(R / 4 - 1);
@@ -3067,8 +3086,8 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
             for (int j = 0; j < RB / 64; j++) r[j] = P.r[j];
         } else {
             const u64 idx = (u64)b * g.nckf + (seg - 1);  // (seg >= nq > 0)
-            st = ckpt_state[idx * 4 + (3 - ql)];
-            u32 po = ckpt_off[idx];
+            u32 po;
+            ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &st, &po);
             p = (int)(po < sbytes ? po : sbytes);
             lo = (p - T) & ~(R / 4 - 1);
 #pragma unroll
@@ -3440,6 +3459,7 @@ struct ansx_merge_desc {
     ansx_merge_part part[ANSX_MERGE_MAX_PARTS];
     u64 ckoff_off, ckstate_off, hint_off, payload_off;  // merged layout (index at 64)
     u32 nparts, nckf;
+    u32 ckw;  // restart-point format of every part and of the result (ansx_dev.h)
 };
 
 // dst[0..n) = src[0..n), any alignment: dword stores on the aligned body of dst, unaligned dword loads
@@ -3462,7 +3482,9 @@ __global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8*
     const ansx_merge_part P = D.part[blockIdx.y];
     const u64 PIECE = 65536;
     // section sizes of this part, in the order they are walked by blockIdx.x
-    const u64 idx_bytes = 8ull * P.nblocks, cko_bytes = 4ull * P.nblocks * D.nckf, cks_bytes = 32ull * P.nblocks * D.nckf;
+    // (packed restart points: one array of 29-byte records where the wide form has its cursors, no state array)
+    const u64 cko_unit = D.ckw ? 4ull : (u64)ANSX_CK_RECORD;
+    const u64 idx_bytes = 8ull * P.nblocks, cko_bytes = cko_unit * P.nblocks * D.nckf, cks_bytes = D.ckw ? 32ull * P.nblocks * D.nckf : 0ull;
     const u64 hint_bytes = 32ull * P.nblocks;
     const u64 n_idx = (idx_bytes + PIECE - 1) / PIECE, n_cko = (cko_bytes + PIECE - 1) / PIECE,
               n_cks = (cks_bytes + PIECE - 1) / PIECE, n_hint = (hint_bytes + PIECE - 1) / PIECE,
@@ -3470,7 +3492,7 @@ __global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8*
     u64 piece = blockIdx.x;
     // part layout (make_plan): index at 64, restart offsets behind the nblocks + 1 index entries
     const u64 p_cko = 64 + 8ull * (P.nblocks + 1);
-    const u64 p_cks = (p_cko + cko_bytes + 7) / 8 * 8;
+    const u64 p_cks = D.ckw ? (p_cko + cko_bytes + 7) / 8 * 8 : p_cko + cko_bytes;
     if (piece < n_idx) {  // block index, rebased
         const u64* src = (const u64*)(P.src + 64);
         u64* dst = (u64*)(out + 64) + P.first_block;
@@ -3482,7 +3504,7 @@ __global__ __launch_bounds__(256) void k_merge_containers(ansx_merge_desc D, u8*
     piece -= n_idx;
     if (piece < n_cko) {
         const u64 lo = piece * PIECE, len = cko_bytes - lo < PIECE ? cko_bytes - lo : PIECE;
-        merge_copy(out + D.ckoff_off + 4ull * P.first_block * D.nckf + lo, P.src + p_cko + lo, len, tid, 256);
+        merge_copy(out + D.ckoff_off + cko_unit * P.first_block * D.nckf + lo, P.src + p_cko + lo, len, tid, 256);
         return;
     }
     piece -= n_cko;

@@ -16,7 +16,8 @@ import struct
 import torch
 
 HEADER_BYTES = 64
-MAGIC = b"ANSXv2\x00\x00"
+MAGIC = b"ANSXv3\x00\x00"
+KIND_WIDE_RESTART = 0x200  # kind word bit 9: u32 cursors + 4 x u64 states instead of packed 29-byte restart points
 
 
 def shard_blocks(n, block_ints, rank, world):
@@ -33,12 +34,18 @@ def shard_blocks(n, block_ints, rank, world):
     return lo, hi - lo
 
 
-def layout(nblocks, ckpts_per_block):
-    """Container layout (must match make_plan() in csrc/ansx.hip)."""
+def layout(nblocks, ckpts_per_block, wide=False):
+    """Container layout (must match layout_of() in csrc/ansx.hip).  Packed restart points (the default): one array of
+    29-byte records where the wide form has its u32 cursors, no separate state array."""
     index_off = HEADER_BYTES
     ckoff_off = index_off + 8 * (nblocks + 1)
-    ckstate_off = (ckoff_off + 4 * nblocks * ckpts_per_block + 7) // 8 * 8
-    hint_off = (ckstate_off + 32 * nblocks * ckpts_per_block + 15) // 16 * 16  # 8 x u32 parse hints per block
+    nck = nblocks * ckpts_per_block
+    if wide:
+        ckstate_off = (ckoff_off + 4 * nck + 7) // 8 * 8
+        hint_off = (ckstate_off + 32 * nck + 15) // 16 * 16  # 8 x u32 parse hints per block
+    else:
+        ckstate_off = ckoff_off
+        hint_off = (ckoff_off + 29 * nck + 15) // 16 * 16
     payload_off = hint_off + 32 * nblocks
     return index_off, ckoff_off, ckstate_off, hint_off, payload_off
 
@@ -114,7 +121,8 @@ def merge_containers(buf, sizes):
             raise ValueError("only the last rank may end in a partial block")
     nblocks = sum(h["nblocks"] for h in hs)
     nckf = h0["ckpts_per_block"]
-    idx_off, ckoff_off, ckstate_off, hint_off, payload_off = layout(nblocks, nckf)
+    wide = bool(h0["kind"] & KIND_WIDE_RESTART)  # (the parts agree: their kind words are equal)
+    idx_off, ckoff_off, ckstate_off, hint_off, payload_off = layout(nblocks, nckf, wide)
     payload_bytes = sum(h["payload_bytes"] for h in hs)
     out = torch.zeros(payload_off + payload_bytes, dtype=torch.uint8, device=dev)
     merged = dict(h0)
@@ -125,13 +133,15 @@ def merge_containers(buf, sizes):
     blk, pay = 0, 0
     index = []
     for p, h in zip(parts, hs):
-        i_off, c_off, s_off, h_off, p_off = layout(h["nblocks"], nckf)
+        i_off, c_off, s_off, h_off, p_off = layout(h["nblocks"], nckf, wide)
         nb = h["nblocks"]
         boff = p[i_off:i_off + 8 * (nb + 1)].clone().view(torch.int64)
         index.append(boff[:nb] + pay)
-        if nckf:
+        if nckf and wide:
             out[ckoff_off + 4 * blk * nckf: ckoff_off + 4 * (blk + nb) * nckf] = p[c_off:c_off + 4 * nb * nckf]
             out[ckstate_off + 32 * blk * nckf: ckstate_off + 32 * (blk + nb) * nckf] = p[s_off:s_off + 32 * nb * nckf]
+        elif nckf:
+            out[ckoff_off + 29 * blk * nckf: ckoff_off + 29 * (blk + nb) * nckf] = p[c_off:c_off + 29 * nb * nckf]
         out[hint_off + 32 * blk: hint_off + 32 * (blk + nb)] = p[h_off:h_off + 32 * nb]
         out[payload_off + pay: payload_off + pay + h["payload_bytes"]] = p[p_off:p_off + h["payload_bytes"]]
         blk += nb

@@ -100,8 +100,11 @@ typedef struct {
 
 /* 64-byte container header (little endian), see DESIGN.md section 3. */
 typedef struct {
-    uint8_t magic[8];       /* "ANSXv2\0\0"                                                    */
-    uint32_t kind;          /* ansx_kind | 0x100 if ANSX_FLAG_COMPACT_ALPHABET                  */
+    uint8_t magic[8];       /* "ANSXv3\0\0"                                                    */
+    uint32_t kind;          /* ansx_kind | 0x100 if ANSX_FLAG_COMPACT_ALPHABET | 0x200 if the restart
+                               points are in the wide form (u32 cursor + 4 x u64 states: ANSint, frames
+                               above 2^16, block streams of 16 MiB and more) instead of packed 29-byte
+                               records (4 x 52-bit states + 24-bit cursor)                       */
     uint32_t fidelity;
     uint64_t n;             /* total ints                                                       */
     uint32_t block_ints;
@@ -155,7 +158,9 @@ int ansx_decode_dev(ansx_ctx* ctx, int kind, int fidelity, const uint8_t* d_in, 
  * list order, every one but the last holding whole blocks only; part_bytes[i] bounds each.  Writes ONE
  * container over all their blocks to d_out (16-byte aligned device memory, which must not overlap the
  * parts): index entries rebased, restart points and payload copied by one HIP kernel.  ansx_decode_dev
- * on the result returns the concatenated list. */
+ * on the result returns the concatenated list.  The parts must agree on the restart-point format too (their
+ * kind words are compared whole); a part that needed the wide form next to parts that did not is refused
+ * (ANSX_ERR_FORMAT) -- encode such inputs with ANSX_WIDE_RESTART set on every rank. */
 int ansx_merge_containers_dev(ansx_ctx* ctx, const uint8_t* const* d_parts, const size_t* part_bytes, int nparts,
     uint8_t* d_out, size_t out_capacity, size_t* out_bytes, void* stream);
 
@@ -192,8 +197,10 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             context's hints for this geometry (largest alphabet; for ANSrfold and the
  *                             compaction layer also the most distinct values a block had, which sizes their
  *                             per-block hash tables), 2 the same with the fused model kernel; + 16: a hint
- *                             did not hold and the call was repeated on the discovery path.  Either way the
- *                             output bytes are the same. */
+ *                             did not hold and the call was repeated on the discovery path; + 32: a frame above
+ *                             2^16 turned up in a call laid out for packed restart points and the call was
+ *                             repeated with wide ones (remembered per geometry).  Either way the output
+ *                             bytes are a function of the input and the options only. */
 typedef struct {
     uint32_t max_nsyms;
     uint32_t max_log2_frame;
@@ -225,7 +232,9 @@ int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t fir
  * learns; too small a value only costs a repeat on the general path), ANSX_T_HINT (number: candidate frame sizes per
  * block of the fast model path), ANSX_NO_FAST_MODEL, ANSX_FAST_GUARD / ANSX_NEAR_BAND (numbers: relative bands around
  * the stop-rule threshold inside which the fast path repeats on the exact one / the host re-decides),
- * ANSX_TEST_NEAR_FLIP (the device decides close calls the wrong way), ANSX_CAND_CHAINS (1 | 2)
+ * ANSX_TEST_NEAR_FLIP (the device decides close calls the wrong way), ANSX_CAND_CHAINS (1 | 2), ANSX_WIDE_RESTART
+ * (wide restart points in every container -- the one switch here that changes the output: the index, not the block
+ * streams), ANSX_TEST_WIDE_AT (number <= 16: frames above 2^this count as too large for packed restart points)
  * (flags: "1" on, "0"/""/NULL off).  Unknown name: ANSX_ERR_ARG. */
 int ansx_debug_set(ansx_ctx* ctx, const char* name, const char* value);
 

@@ -6,7 +6,7 @@ import numpy as np
 
 import oracle_lib as ol
 
-MAGIC = b"ANSXv2\x00\x00"
+MAGIC = b"ANSXv3\x00\x00"
 
 
 def nseg(nb, ckpt):
@@ -16,7 +16,20 @@ def nseg(nb, ckpt):
     return (nfull + ckpt - 1) // ckpt
 
 
-def build_container(kind, f, data, block, ckpt):
+def pack_restart_points(states, offs):
+    """(n, 4) u64 states + n u32 cursors -> n records of 29 bytes: states 0, 1 as one 104-bit little-endian integer
+    (state 0 in the low 52 bits), states 2, 3 likewise, then the cursor in 24 bits."""
+    out = bytearray()
+    for st, off in zip(states.tolist(), offs.tolist()):
+        assert all(x < (1 << 52) for x in st) and off < (1 << 24)
+        out += (st[0] | (st[1] << 52)).to_bytes(13, "little")
+        out += (st[2] | (st[3] << 52)).to_bytes(13, "little")
+        out += off.to_bytes(3, "little")
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def build_container(kind, f, data, block, ckpt, wide=None):
+    """wide: restart-point format; None = what the library picks (wide for ANSint and once a frame exceeds 2^16)."""
     data = np.ascontiguousarray(data, dtype=np.uint32)
     n = data.size
     if ckpt >= block:
@@ -36,22 +49,29 @@ def build_container(kind, f, data, block, ckpt):
         cko.append(pad_o)
         maxlg = max(maxlg, info.log2_frame)
         maxns = max(maxns, info.max_sym + 1)
+    if wide is None:
+        wide = (kind & 0xFF) == 3 or maxlg > 16
     index_off = 64
     ckoff_off = index_off + 8 * (nblocks + 1)
-    ckstate_off = (ckoff_off + 4 * nblocks * nckf + 7) // 8 * 8
-    hint_off = (ckstate_off + 32 * nblocks * nckf + 15) // 16 * 16
+    if wide:
+        ckstate_off = (ckoff_off + 4 * nblocks * nckf + 7) // 8 * 8
+        hint_off = (ckstate_off + 32 * nblocks * nckf + 15) // 16 * 16
+    else:
+        hint_off = (ckoff_off + 29 * nblocks * nckf + 15) // 16 * 16
     payload_off = hint_off + 32 * nblocks
     sizes = np.array([s.size for s in streams], dtype=np.uint64)
     boff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     payload = np.concatenate(streams)
     out = np.zeros(payload_off + payload.size, dtype=np.uint8)
-    hdr = MAGIC + struct.pack("<IIQIIIIIIQQ", kind, f, n, block, ckpt, nblocks, maxlg, maxns, nckf,
+    hdr = MAGIC + struct.pack("<IIQIIIIIIQQ", kind | (0x200 if wide else 0), f, n, block, ckpt, nblocks, maxlg, maxns, nckf,
                               int(payload.size), payload_off)
     out[:64] = np.frombuffer(hdr, dtype=np.uint8)
     out[index_off:index_off + 8 * (nblocks + 1)] = boff.view(np.uint8)
-    if nckf:
+    if nckf and wide:
         out[ckoff_off:ckoff_off + 4 * nblocks * nckf] = np.concatenate(cko).view(np.uint8)
         out[ckstate_off:ckstate_off + 32 * nblocks * nckf] = np.concatenate(cks).reshape(-1).view(np.uint8)
+    elif nckf:
+        out[ckoff_off:ckoff_off + 29 * nblocks * nckf] = pack_restart_points(np.concatenate(cks), np.concatenate(cko))
     out[hint_off:hint_off + 32 * nblocks] = np.concatenate(hints).view(np.uint8)
     out[payload_off:] = payload
     return out

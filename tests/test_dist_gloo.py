@@ -55,6 +55,12 @@ def test_layout_matches_python_container(oracle_built):
     assert h["n"] == data.size and h["nblocks"] == 5 and h["ckpts_per_block"] == 3
     assert adist.layout(h["nblocks"], h["ckpts_per_block"])[4] == h["payload_offset"]
     assert adist.pack_header(h) == c[:64].tobytes()
+    # wide restart points (kind word bit 9): the v2 arrays
+    w = cp.build_container(ol.FOLD, 1, data, 4096, 1024, wide=True)
+    hw = adist.parse_header(torch.from_numpy(w))
+    assert hw["kind"] == (ol.FOLD | adist.KIND_WIDE_RESTART)
+    assert adist.layout(hw["nblocks"], hw["ckpts_per_block"], wide=True)[4] == hw["payload_offset"]
+    assert w.size - c.size == hw["payload_offset"] - h["payload_offset"] > 0
 
 
 @pytest.mark.timeout(300)

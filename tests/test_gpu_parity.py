@@ -77,7 +77,7 @@ def check_container(A, cont, data, kind, f, block, ckpt):
     H = parts["header"]
     n = data.size
     nblocks = (n + block - 1) // block
-    assert H.n == n and H.nblocks == nblocks and H.block_ints == block and H.kind == kind and H.fidelity == f
+    assert H.n == n and H.nblocks == nblocks and H.block_ints == block and (H.kind & ~0x200) == kind and H.fidelity == f  # (bit 9: restart-point format)
     max_lg, max_ns = 0, 0
     for b in range(nblocks):
         blk = data[b * block:(b + 1) * block]
@@ -427,6 +427,85 @@ def test_whole_container_equals_python_builder(A, ctx):
         got = codec.encode(data)
         exp = cp.build_container(kind, f, data, block, ck)
         assert got.size == exp.size and np.array_equal(got, exp), (kind, f)
+
+
+def test_restart_point_formats(A):
+    """Container v3: packed 29-byte restart points by default (4 x 52-bit states + 24-bit cursor), the wide form (u32 +
+    4 x u64) where a frame may exceed 2^16.  Both against the Python builder, both decoded, both merged (native kernel
+    and the torch restatement); a call that meets too large a frame half way is repeated with wide restart points and
+    the context remembers that for the geometry; parts in different formats do not merge."""
+    import container_py as cp
+    torch = pytest.importorskip("torch")
+    from ans_large_alphabet_amd import dist as adist
+
+    n, block, ck = 70001, 8192, 1024
+    data = ol.gen_inputs("zipf20s1.2", n, seed=77)
+    exp_packed = cp.build_container(ol.FOLD, 1, data, block, ck)
+    exp_wide = cp.build_container(ol.FOLD, 1, data, block, ck, wide=True)
+    assert exp_wide.size > exp_packed.size
+    # (1) packed is what a fresh context writes; states of frames of exactly 2^16 use all 52 bits
+    c0 = A.Context(0)
+    codec = A.ANSfold(1, ctx=c0, block_ints=block, ckpt_interval=ck)
+    got = codec.encode(data)
+    assert np.array_equal(got, exp_packed)
+    assert np.array_equal(codec.decode(got, n), data)
+    parts = A.parse_container(got)
+    assert not (parts["header"].kind & 0x200) and parts["ckpt_state"].shape == (9, 7, 4)
+    c0.close()
+    # (2) the wide form on request
+    c1 = A.Context(0)
+    c1.debug_set("ANSX_WIDE_RESTART", "1")
+    codec = A.ANSfold(1, ctx=c1, block_ints=block, ckpt_interval=ck)
+    for _ in range(2):  # (discovery call, then the hinted fast path)
+        got_w = codec.encode(data)
+        assert np.array_equal(got_w, exp_wide)
+    assert np.array_equal(codec.decode(got_w, n), data)
+    pw = A.parse_container(got_w)
+    assert pw["header"].kind & 0x200
+    assert np.array_equal(pw["ckpt_state"], parts["ckpt_state"]) and np.array_equal(pw["ckpt_off"], parts["ckpt_off"])
+    # merge of wide parts: native kernel == torch restatement == whole encode
+    shards, sizes, bufs = [], [], []
+    for r in range(3):
+        lo, cnt = adist.shard_blocks(n, block, r, 3)
+        c = codec.encode(data[lo:lo + cnt])
+        shards.append(c)
+        sizes.append(c.size)
+        bufs.append(torch.from_numpy(np.concatenate([c, np.zeros((-c.size) % 16, np.uint8)])).cuda())
+    out = torch.empty(exp_wide.size + 64, dtype=torch.uint8, device="cuda:0")
+    nb = c1.merge_containers_dev([b.data_ptr() for b in bufs], sizes, out.data_ptr(), out.numel())
+    assert np.array_equal(out[:nb].cpu().numpy(), exp_wide)
+    pym = adist.merge_containers(torch.cat([torch.from_numpy(c.copy()) for c in shards]), sizes).numpy()
+    assert np.array_equal(pym, exp_wide)
+    # a packed part among wide ones is refused
+    c0 = A.Context(0)
+    lo, cnt = adist.shard_blocks(n, block, 1, 3)
+    pk = A.ANSfold(1, ctx=c0, block_ints=block, ckpt_interval=ck).encode(data[lo:lo + cnt])
+    tb = torch.from_numpy(np.concatenate([pk, np.zeros((-pk.size) % 16, np.uint8)])).cuda()
+    with pytest.raises(A.AnsxError) as e:
+        c1.merge_containers_dev([bufs[0].data_ptr(), tb.data_ptr(), bufs[2].data_ptr()], [sizes[0], pk.size, sizes[2]], out.data_ptr(), out.numel())
+    assert e.value.status == 3  # ANSX_ERR_FORMAT
+    c0.close()
+    c1.close()
+    # (3) a frame "too large" for packed restart points turns up during the call (threshold lowered for the test: the
+    # real one, 2^16, is out of reach of the fold codecs' alphabets): repeated wide, then wide from the start
+    c2 = A.Context(0)
+    c2.debug_set("ANSX_TEST_WIDE_AT", "9")
+    codec = A.ANSfold(1, ctx=c2, block_ints=block, ckpt_interval=ck)
+    assert np.array_equal(codec.encode(data), exp_wide)
+    assert c2.last_encode_stats()["path"] & 32
+    assert np.array_equal(codec.encode(data), exp_wide)
+    assert not (c2.last_encode_stats()["path"] & 32)
+    assert np.array_equal(codec.decode(exp_wide, n), data)
+    c2.close()
+    # (4) ANSint (32-bit frequencies, frames up to 2^27) always takes the wide form
+    c3 = A.Context(0)
+    vals = (ol.gen_inputs("zipf20s1.2", 30000, seed=5) % 3000).astype(np.uint32)
+    ci = A.ANSint(ctx=c3, block_ints=8192, ckpt_interval=1024, compact=False)
+    gi = ci.encode(vals)
+    assert A.parse_container(gi)["header"].kind == (ol.INT | 0x200)
+    assert np.array_equal(gi, cp.build_container(ol.INT, 0, vals, 8192, 1024))
+    assert np.array_equal(ci.decode(gi, vals.size), vals)
+    c3.close()
 
 
 def test_rank_shards_merge_into_one_decodable_container(A, ctx):
@@ -1108,7 +1187,7 @@ def test_compacted_blocks_match_oracle(A, ctx, kind, f, fam):
     cont = codec.encode(data)
     parts = A.parse_container(cont)
     H = parts["header"]
-    assert H.kind == (kind | 0x100) and H.nblocks == 6 and H.n == n
+    assert H.kind == (kind | 0x100 | (0x200 if kind == ol.INT else 0)) and H.nblocks == 6 and H.n == n  # (ANSint: wide restart points)
     for b in range(H.nblocks):
         blk = data[b * block:(b + 1) * block]
         exp, pinfo, info, st, off = ol.oracle_pa_encode(kind, f, blk, ckpt_interval=ckpt)

@@ -928,11 +928,15 @@ struct ansx_code {
 
 // Exclusive prefix sum of one value per thread over a workgroup of NT threads (NT a multiple of
 // 64, <= 1024): wave scan over shuffles, wave totals through LDS.  *total = sum over the group.
-// wsum: NT/64 + 1 words of LDS scratch.  Contains two barriers.
+// wsum: NT/64 + 1 words of LDS scratch.  Contains two barriers (none for a single-wave workgroup).
 template <typename T> __device__ __forceinline__ T block_excl_scan(T v, T* wsum, u32 tid, u32 nt, T* total)
 {
     const T incl = wave_incl_scan(v);
     const u32 nw = nt >> 6;
+    if (nw == 1) {  // a single wave: no LDS, no barrier
+        *total = wave_last(incl);
+        return incl - v;
+    }
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
     if (tid < 64) {

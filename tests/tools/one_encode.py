@@ -20,4 +20,15 @@ for i in range(6):
     except Exception as e:
         print("encode", i, "failed:", str(e)[:80])
 torch.cuda.synchronize()
+back = torch.empty(n, dtype=torch.int32, device="cuda:0")
+try:
+    nbytes = codec.encode_dev(d.data_ptr(), n, out.data_ptr(), out.numel())
+    for i in range(6):
+        try:
+            codec.decode_dev(out.data_ptr(), nbytes, back.data_ptr(), n)
+        except Exception as e:
+            print("decode", i, "failed:", str(e)[:80])
+except Exception as e:
+    print("encode for the decode leg failed:", str(e)[:80])
+torch.cuda.synchronize()
 print("done")

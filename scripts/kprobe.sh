@@ -3,7 +3,9 @@
 set -o pipefail
 K=$1; shift
 export TMPDIR=/tmp
+cd "$(dirname "$(readlink -f "$0")")/.."
 cp ans_large_alphabet_amd/libansx.so /tmp/libansx_orig.so
+trap 'cp /tmp/libansx_orig.so ans_large_alphabet_amd/libansx.so' EXIT
 for v in /tmp/libansx_orig.so variants/libansx_*.so; do
   tag=$(basename $v .so | sed 's/libansx_//')
   [ $v != /tmp/libansx_orig.so ] && cp $v ans_large_alphabet_amd/libansx.so
@@ -18,4 +20,3 @@ for f in sys.argv[3:]:
 PY
   tail -2 /tmp/kp_$tag.log | grep -v "^done" | cut -c1-200
 done
-cp /tmp/libansx_orig.so ans_large_alphabet_amd/libansx.so

@@ -35,13 +35,17 @@ blocks = [(16384, 1024), (16384, 256), (4096, 512), (65536, 1024), (8192, 2048),
 t0 = time.time(); it = 0; fails = 0; near = 0
 while time.time() - t0 < budget:
     it += 1
-    kind, f = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0)][int(rng.integers(0, 7))]
+    kind, f = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0), (ol.INT, 0)][int(rng.integers(0, 8))]
     block, ckpt = blocks[int(rng.integers(0, len(blocks)))]
     n = int(rng.integers(1, 1 << int(rng.integers(4, 22))))
     data = gen(kind, n)
     if kind == ol.RFOLD: data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    if kind == ol.INT:  # plain ANSint: the values are the symbols (below 16384), at least two distinct ones
+        data = (data % np.uint32(int(rng.integers(2, 16384)))).astype(np.uint32)
+        if n < 2 or data.min() == data.max(): continue
     cls = {ol.FOLD: A.ANSfold, ol.RFOLD: A.ANSrfold}.get(kind)
-    codec = A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt) if kind == ol.MSB else cls(f, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    if kind == ol.INT: codec = A.ANSint(ctx=ctx, block_ints=block, ckpt_interval=ckpt, compact=False)
+    else: codec = A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt) if kind == ol.MSB else cls(f, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
     try:
         cont = codec.encode(data)
         near += ctx.last_encode_stats()["near_threshold_decisions"]
@@ -50,9 +54,13 @@ while time.time() - t0 < budget:
         if ok and n <= 300000 and it % 3 == 0:   # oracle parity of every block stream (CPU cost)
             parts = A.parse_container(cont)
             for b in range(parts["header"].nblocks):
-                exp = ol.oracle_encode(kind, f, data[b * block:(b + 1) * block], ckpt_interval=ckpt)[0]
+                exp, _, est, eoff = ol.oracle_encode(kind, f, data[b * block:(b + 1) * block], ckpt_interval=0 if ckpt >= block else ckpt)
                 if not np.array_equal(parts["streams"][b], exp): ok = False; break
+                # restart points (29-byte records, or the wide form for ANSint): states and cursors as the oracle has them
+                k = est.shape[0]
+                if not (np.array_equal(parts["ckpt_state"][b][:k], est) and np.array_equal(parts["ckpt_off"][b][:k], eoff)): ok = False; break
     except Exception as e:
+        if kind == ol.INT and getattr(e, "status", None) == 7: continue  # ANSX_ERR_MODEL: a constant block under ANSint (the reference does not terminate on it)
         ok = False; print("EXC", repr(e))
     if not ok:
         fails += 1

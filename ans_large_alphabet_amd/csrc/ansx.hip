@@ -508,15 +508,21 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)
     const u32 sort_cap = (optimistic && h_deferred) ? std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 7u) & ~7u)) : NSP;
-    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)sort_cap * 4 + (h_deferred ? 0 : 512 * 8);
-    if (k2a_lds > 32 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy,
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
+    const bool sort16 = g.block_ints <= 65535u;  // (a count fits 16 bits: half the staged row)
+    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)sort_cap * (sort16 ? 2 : 4) + (h_deferred ? 0 : 512 * 8);
+    if (k2a_lds > 32 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
+    }
     if ((size_t)NSP * 8 + 64 > 48 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
-    LAUNCH(c, "k_sort_entropy", k_sort_entropy, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
-        (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
+    if (sort16)
+        LAUNCH(c, "k_sort_entropy", k_sort_entropy<u16>, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
+            (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
+    else
+        LAUNCH(c, "k_sort_entropy", k_sort_entropy<u32>, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
+            (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
     // Frame sizes M0*2^t are tried ANSX_ATTEMPTS at a time.  Almost every block settles in the
     // first batch; the count of undecided blocks comes back with the words the encoder launch
     // needs anyway (largest alphabet / frame), so further batches are launched only on demand.
@@ -557,15 +563,20 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
 #undef ANSX_LAUNCH_CAND2
         const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
         const size_t fl = (size_t)fcap * 12 + 64;
+#define ANSX_LAUNCH_FIN(IPT_, NTC_)                                                                                    \
+    do {                                                                                                            \
+        if (fl > 48 * 1024)                                                                                         \
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<IPT_, NTC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+        LAUNCH(c, "k_model_finish", (k_model_finish<IPT_, NTC_>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p, \
+            (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo); \
+    } while (0)
         if (NSP <= 1024) {
-            LAUNCH(c, "k_model_finish", (k_model_finish<4>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo);
+            ANSX_LAUNCH_FIN(4, 8);  // (wave-per-candidate form: NTC is not used)
         } else {
-            if (fl > 48 * 1024)
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
-            LAUNCH(c, "k_model_finish", (k_model_finish<16>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
-                (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo);
+            if (NT <= 5) ANSX_LAUNCH_FIN(16, 5);
+            else ANSX_LAUNCH_FIN(16, 8);
         }
+#undef ANSX_LAUNCH_FIN
         max_logM = 16;
         max_ns = ns_cap;
     }

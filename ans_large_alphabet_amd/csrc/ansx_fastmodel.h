@@ -256,15 +256,17 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
 // Cross entropy of the NT candidates of k_candidates and the stop rule over them (guard band, see the header of this
 // file), then the chosen frequencies by symbol, their exclusive scan (encoder table, compact 4-byte form; thread i
 // owns IPT consecutive symbols) and the prelude (prelude_emit of ansx_kernels.h).  One workgroup of 256 threads per
-// block.  XH_t = log2 M_t - (sum_j F_j log2 S_t,j) / n: wave w takes the candidates t = w, w + 4, its lane l the
-// 8-rank chunks l, l + 64, ...; a shuffle reduction per candidate.  The first chunk of every lane, the candidates'
-// {ok, maxS} words and a lane's share of the log2 table's first ANSX_FIN_LUT entries (for LDS) are requested together
-// with the block's fields, before anything is known about the block: one round trip for alphabets up to 512 symbols.
-// The wave that holds the chosen candidate then scatters its chunks -- rank order -> symbol order -- into LDS.
+// block.  XH_t = log2 M_t - (sum_j F_j log2 S_t,j) / n: thread i takes the 8-rank chunk i (and i + 256, ...) for ALL
+// candidates -- their frequencies of a chunk are neighbours in memory -- so the chunk, the candidates' {ok, maxS} words
+// and a thread's share of the log2 table's first ANSX_FIN_LUT entries (for LDS) are requested together with the block's
+// fields, before anything is known about the block: one round trip for alphabets up to 2048 symbols, and the chosen
+// candidate is later scattered -- rank order -> symbol order -- into LDS from those same registers.  (Until the end of
+// round 3 a wave took one or two candidates and looped over the chunks with a load per iteration: a dependent round
+// trip per 512 symbols in the sum and again in the scatter.)  NTC: compile-time bound of NT (5 or 8 registers sets).
 // Anything this path does not cover raises the violation flag and leaves the block without a stream; the host
 // repeats the call on the exact path: undecided after NT candidates, the u16 exit with no earlier success, a
 // frame above 2^16, a comparison inside the guard band (`guard`: ANSX_FAST_GUARD; tests widen it to force the repeat).
-template <int IPT>
+template <int IPT, int NTC>
 __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 NT, const uint2* __restrict__ pairs,
     const uint4* __restrict__ srank, const u32* __restrict__ attMeta, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
@@ -273,10 +275,12 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
 {
     static_assert(IPT % 4 == 0, "table rows are written 16 bytes at a time");
     static_assert(ANSX_FIN_LUT == 512, "two table entries per thread");
+    static_assert(NTC >= 4 && NTC <= (int)ANSX_ATTEMPTS, "candidates per block");
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
     __shared__ double lut[ANSX_FIN_LUT];
-    __shared__ double wsum[ANSX_ATTEMPTS];
+    __shared__ double wpart[ANSX_ATTEMPTS][4];  // per candidate and wave: partial sum of F log2 S
+    __shared__ double wsum[ANSX_ATTEMPTS];      // XH of every candidate
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const u32 b = blockIdx.x;
     ansx_blk* B = &blk[b];
@@ -285,7 +289,10 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     u32* inc = lds32 + 2 * cap;   // [cap]
     u32* frq = bits;
     STAMP(0);
-    // ---- requests
+    // ---- requests: everything the cross entropy of ALL candidates needs of 8-rank chunk `tid` -- its (F | sym << 16)
+    // words and the NT candidates' frequencies, which lie next to each other (srank[block][chunk][t]) -- together with
+    // the block's fields, before anything is known about the block: one round trip, whatever the alphabet up to 2048
+    // symbols.  (NT <= NTC; candidates at or above NT are loaded from candidate 0's address and ignored.)
     const u32 ns = B->max_sym + 1;
     const u32 sigma = B->sigma;
     const double thr = B->thr;
@@ -295,11 +302,32 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
 #pragma unroll
     for (u32 t = 0; t < ANSX_ATTEMPTS; t++) mt[t] = t < NT ? *(const uint2*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) : make_uint2(0u, 0u);
     const double2 l2 = *(const double2*)(lg2i + 2 * tid);
+    const uint2* prow = pairs + (u64)b * NSP;
+    auto load_fs = [&](u32 c, u32 (&fs)[8]) {
+        const uint2* pp = prow + (u64)c * 8u;
+        const uint4 a0 = *(const uint4*)pp, a1 = *(const uint4*)(pp + 2), a2 = *(const uint4*)(pp + 4), a3 = *(const uint4*)(pp + 6);
+        fs[0] = a0.x, fs[1] = a0.z, fs[2] = a1.x, fs[3] = a1.z, fs[4] = a2.x, fs[5] = a2.z, fs[6] = a3.x, fs[7] = a3.z;
+    };
+    auto load_s = [&](u32 c, uint4 (&sv)[NTC]) {
+#pragma unroll
+        for (int t = 0; t < NTC; t++) sv[t] = srank[srank_chunk(NSP, NT, b, c, (u32)t < NT ? (u32)t : 0u)];
+    };
+    // Alphabets up to 1024 slots (IPT == 4) keep the round-3 form -- wave w takes the candidates w and w + 4, lane l
+    // the chunks l, l + 64 -- because the all-candidates form needs 96 registers instead of 66 (5 instead of 7 waves per
+    // SIMD) and measured slower there (0.175 vs 0.155 ms); on 4096-slot alphabets it is the faster one (0.38 -> 0.34).
+    constexpr bool ALLT = IPT > 4;
+    u32 fs0[8] = {};
+    uint4 sv0[NTC] = {};
+    if constexpr (ALLT) {
+        if (tid < (NSP >> 3)) {  // (wave-uniform: NSP / 8 is a multiple of 64)
+            load_fs(tid, fs0);
+            load_s(tid, sv0);
+        }
+    }
     struct chunk {
         uint4 fa, fb;  // (freq | sym << 16) of the chunk's 8 ranks
         uint4 s;       // one candidate's 8 frequencies
     };
-    const uint2* prow = pairs + (u64)b * NSP;
     auto load_chunk = [&](u32 c, u32 t) -> chunk {
         const uint2* pp = prow + (u64)c * 8u;
         const uint4 a0 = *(const uint4*)pp, a1 = *(const uint4*)(pp + 2), a2 = *(const uint4*)(pp + 4), a3 = *(const uint4*)(pp + 6);
@@ -309,11 +337,14 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         k.s = srank[srank_chunk(NSP, NT, b, c, t)];
         return k;
     };
-    // first chunk of this lane for the wave's one or two candidates (chunk index lane < NSP / 8 always: NSP >= 512)
     const u32 t0 = wv, t1 = wv + 4u;
-    const chunk k0 = load_chunk(lane, t0 < NT ? t0 : 0u);
-    chunk k1 = k0;  // (the same ranks: only the candidate's frequencies differ)
-    if (t1 < NT) k1.s = srank[srank_chunk(NSP, NT, b, lane, t1)];
+    chunk k0 = {}, k1 = {};
+    if constexpr (!ALLT) {
+        // first chunk of this lane for the wave's one or two candidates (chunk index lane < NSP / 8 always: NSP >= 512)
+        k0 = load_chunk(lane, t0 < NT ? t0 : 0u);
+        k1 = k0;  // (the same ranks: only the candidate's frequencies differ)
+        if (t1 < NT) k1.s = srank[srank_chunk(NSP, NT, b, lane, t1)];
+    }
     if (B->status) {  // (k_sort_entropy: alphabet above the hint -- violation already raised)
         if (tid == 0) B->prelude_bytes = 0;
         return;
@@ -323,11 +354,10 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     STAMP(1);
     __syncthreads();
     STAMP(2);
-    // ---- cross entropy of the wave's candidates
+    // ---- cross entropy: XH_t = log2 M_t - (sum_j F_j log2 S_t,j) / n, every thread its chunk for all candidates
     const u32 nchunks = (sigma + 7u) >> 3;
-    auto xh_chunk = [&](const chunk& k, u32 c) -> double {
-        const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
-        const u32 sv8[8] = { k.s.x & 0xFFFFu, k.s.x >> 16, k.s.y & 0xFFFFu, k.s.y >> 16, k.s.z & 0xFFFFu, k.s.z >> 16, k.s.w & 0xFFFFu, k.s.w >> 16 };
+    auto xh8 = [&](const u32 (&fs)[8], const uint4& sq) -> double {
+        const u32 sv8[8] = { sq.x & 0xFFFFu, sq.x >> 16, sq.y & 0xFFFFu, sq.y >> 16, sq.z & 0xFFFFu, sq.z >> 16, sq.w & 0xFFFFu, sq.w >> 16 };
         // (a value that was above 65535 is seen truncated: such a candidate ends in the u16 exit before its XH is looked at)
         u32 big = 0;
 #pragma unroll
@@ -336,35 +366,70 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         double w = 0.0;
         if (big < ANSX_FIN_LUT) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs8[i] & 0xFFFFu), lut[sv8[i]], w);
+            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs[i] & 0xFFFFu), lut[sv8[i]], w);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs8[i] & 0xFFFFu), lg2i[sv8[i]], w);
+            for (int i = 0; i < 8; i++) w = __builtin_fma((double)(fs[i] & 0xFFFFu), lg2i[sv8[i]], w);
         }
         return w;
     };
-    auto scatter = [&](const chunk& k, u32 c) {
-        const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
-        const u32 sv8[8] = { k.s.x & 0xFFFFu, k.s.x >> 16, k.s.y & 0xFFFFu, k.s.y >> 16, k.s.z & 0xFFFFu, k.s.z >> 16, k.s.w & 0xFFFFu, k.s.w >> 16 };
+    auto scatter = [&](const u32 (&fs)[8], const uint4& sq, u32 c) {
+        const u32 sv8[8] = { sq.x & 0xFFFFu, sq.x >> 16, sq.y & 0xFFFFu, sq.y >> 16, sq.z & 0xFFFFu, sq.z >> 16, sq.w & 0xFFFFu, sq.w >> 16 };
         // (symbols of a block are below ns <= cap; ranks past sigma go to a scratch word behind the three arrays)
 #pragma unroll
-        for (int i = 0; i < 8; i++) frq[c * 8u + i < sigma ? fs8[i] >> 16 : 2u * cap + 8u] = sv8[i];
+        for (int i = 0; i < 8; i++) frq[c * 8u + i < sigma ? fs[i] >> 16 : 2u * cap + 8u] = sv8[i];
     };
-    double w0 = 0.0, w1 = 0.0;
-    if (t0 < NT) {
-        if (lane < nchunks) w0 = xh_chunk(k0, lane);
-        for (u32 c = lane + 64u; c < nchunks; c += 64u) w0 = w0 + xh_chunk(load_chunk(c, t0), c);
-        w0 = wave_sum(w0);
-        if (lane == 0) wsum[t0] = (double)(m0 + t0) - w0 / nd;  // XH of candidate t0 (one division per wave, not per thread and candidate)
+    if constexpr (ALLT) {
+        double w[NTC];
+#pragma unroll
+        for (int t = 0; t < NTC; t++) w[t] = 0.0;
+        if (tid < nchunks) {  // (nchunks <= NSP / 8: the chunk was loaded)
+#pragma unroll
+            for (int t = 0; t < NTC; t++)
+                if ((u32)t < NT) w[t] = xh8(fs0, sv0[t]);
+        }
+        for (u32 c = tid + 256u; c < nchunks; c += 256u) {  // alphabets above 2048 symbols: a second round trip
+            u32 fs1[8];
+            uint4 s1[NTC];
+            load_fs(c, fs1);
+            load_s(c, s1);
+#pragma unroll
+            for (int t = 0; t < NTC; t++)
+                if ((u32)t < NT) w[t] = w[t] + xh8(fs1, s1[t]);
+        }
+        if (wv * 64u < nchunks || nchunks > 256u) {  // (waves without a chunk have nothing to add)
+#pragma unroll
+            for (int t = 0; t < NTC; t++) {
+                if ((u32)t >= NT) continue;
+                const double ws = wave_sum(w[t]);
+                if (lane == 0) wpart[t][wv] = ws;
+            }
+        } else if (lane < NTC) wpart[lane][wv] = 0.0;
+        STAMP(3);
+        __syncthreads();
+        if (tid < NT) wsum[tid] = (double)(m0 + tid) - ((wpart[tid][0] + wpart[tid][1]) + (wpart[tid][2] + wpart[tid][3])) / nd;  // one division per candidate
+        __syncthreads();
+    } else {
+        auto xh_chunk = [&](const chunk& k) -> double {
+            const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
+            return xh8(fs8, k.s);
+        };
+        double w0 = 0.0, w1 = 0.0;
+        if (t0 < NT) {
+            if (lane < nchunks) w0 = xh_chunk(k0);
+            for (u32 c = lane + 64u; c < nchunks; c += 64u) w0 = w0 + xh_chunk(load_chunk(c, t0));
+            w0 = wave_sum(w0);
+            if (lane == 0) wsum[t0] = (double)(m0 + t0) - w0 / nd;  // XH of candidate t0 (one division per wave, not per thread and candidate)
+        }
+        if (t1 < NT) {
+            if (lane < nchunks) w1 = xh_chunk(k1);
+            for (u32 c = lane + 64u; c < nchunks; c += 64u) w1 = w1 + xh_chunk(load_chunk(c, t1));
+            w1 = wave_sum(w1);
+            if (lane == 0) wsum[t1] = (double)(m0 + t1) - w1 / nd;
+        }
+        STAMP(3);
+        __syncthreads();
     }
-    if (t1 < NT) {
-        if (lane < nchunks) w1 = xh_chunk(k1, lane);
-        for (u32 c = lane + 64u; c < nchunks; c += 64u) w1 = w1 + xh_chunk(load_chunk(c, t1), c);
-        w1 = wave_sum(w1);
-        if (lane == 0) wsum[t1] = (double)(m0 + t1) - w1 / nd;
-    }
-    STAMP(3);
-    __syncthreads();
     STAMP(4);
     // ---- the (workgroup-uniform) rule, on the same NT results in every thread
     int chosen = -2, prev = -1;
@@ -391,10 +456,27 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         }
         return;
     }
-    // ---- chosen frequencies: rank order -> symbol order through LDS, by the wave that holds them
-    if ((u32)chosen == t0 || (u32)chosen == t1) {
-        if (lane < nchunks) scatter((u32)chosen == t0 ? k0 : k1, lane);
-        for (u32 c = lane + 64u; c < nchunks; c += 64u) scatter(load_chunk(c, (u32)chosen), c);
+    // ---- chosen frequencies: rank order -> symbol order through LDS, from the registers that hold them
+    if constexpr (ALLT) {
+        if (tid < nchunks) {
+            uint4 sc = sv0[0];
+#pragma unroll
+            for (int t = 1; t < NTC; t++)
+                if (chosen == t) sc = sv0[t];
+            scatter(fs0, sc, tid);
+        }
+        for (u32 c = tid + 256u; c < nchunks; c += 256u) {
+            u32 fs1[8];
+            load_fs(c, fs1);
+            scatter(fs1, srank[srank_chunk(NSP, NT, b, c, (u32)chosen)], c);
+        }
+    } else if ((u32)chosen == t0 || (u32)chosen == t1) {  // ... by the wave that holds them
+        auto scatter_chunk = [&](const chunk& k, u32 c) {
+            const u32 fs8[8] = { k.fa.x, k.fa.y, k.fa.z, k.fa.w, k.fb.x, k.fb.y, k.fb.z, k.fb.w };
+            scatter(fs8, k.s, c);
+        };
+        if (lane < nchunks) scatter_chunk((u32)chosen == t0 ? k0 : k1, lane);
+        for (u32 c = lane + 64u; c < nchunks; c += 64u) scatter_chunk(load_chunk(c, (u32)chosen), c);
     }
     STAMP(5);
     __syncthreads();

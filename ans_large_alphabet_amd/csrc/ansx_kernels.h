@@ -304,6 +304,9 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // pairs != nullptr (the fast model path, blocks of at most 65535 ints): instead of sortF / sortSym the kernel writes
 // one uint2 per rank: { freq | sym << 16, fs_rem } with fs_rem = n - (sum of the frequencies ranked before it),
 // the divisor of that symbol's scale_freqs step (ans_util.hpp:83), so that k_candidates can prepare its reciprocal.
+// HT: type of the staged row -- u16 for blocks of at most 65535 values (a count cannot exceed the block length): half
+// the dynamic LDS, i.e. more blocks per CU for this occupancy-bound kernel.
+template <typename HT>
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk, u32 cap, uint2* __restrict__ pairs, u32* __restrict__ gflags)
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     __shared__ u32 wadj[ANSX_VMAX];  // packed output: (frequency mass ranked before the value's bin) - (bin start) * value
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
-    u32* hrow = (u32*)(lds_k2a + nbig_cap);  // [cap] this block's histogram row
+    HT* hrow = (HT*)(lds_k2a + nbig_cap);  // [cap] this block's histogram row
     double* terms = (double*)(hrow + cap);   // [512], only allocated when the entropy is summed here
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     uint2* oP = pairs ? pairs + (u64)b * NSP : nullptr;
 #pragma unroll
     for (u32 r = 0; r < SORT_PRE; r++)
-        if (r * 64 + lane < ns) hrow[r * 64 + lane] = hp[r];
-    for (u32 s = SORT_PRE * 64 + lane; s < ns; s += 64) hrow[s] = h[s];
+        if (r * 64 + lane < ns) hrow[r * 64 + lane] = (HT)hp[r];
+    for (u32 s = SORT_PRE * 64 + lane; s < ns; s += 64) hrow[s] = (HT)h[s];
     for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
     for (u32 v = lane; v < ANSX_MASKV; v += 64) vmask[v] = 0;
     if (lane == 0) sh_nbig = 0;

@@ -71,6 +71,39 @@ def test_container_info_rejects_garbage(A):
     assert A.lib().ansx_container_info(buf.ctypes.data, 10, C.byref(H)) == _lib.ERR_FORMAT
 
 
+def test_container_v3_host_side(A, oracle_built):
+    """Container v3 without a GPU: the Python builder's container is accepted by ansx_container_info in both
+    restart-point formats, parse_container unpacks the 29-byte records to the states and cursors that went in
+    (4 x 52-bit states, 24-bit cursor; extremes included), v2 is refused."""
+    import container_py as cp
+    import oracle_lib as ol
+
+    rng = np.random.default_rng(3)
+    st = rng.integers(0, 1 << 52, size=(37, 4), dtype=np.uint64)
+    st[0] = (1 << 52) - 1
+    st[1] = 0
+    off = rng.integers(0, 1 << 24, size=37, dtype=np.uint32)
+    off[0], off[1] = (1 << 24) - 1, 0
+    raw = cp.pack_restart_points(st, off)
+    assert raw.size == 37 * 29
+    o2, s2 = A.codec.unpack_restart_points(raw)
+    assert np.array_equal(o2, off) and np.array_equal(s2.reshape(-1, 4), st)
+    data = ol.gen_inputs("zipf20s1.2", 20001, seed=2)
+    for wide in (False, True):
+        c = cp.build_container(ol.FOLD, 1, data, 4096, 1024, wide=wide)
+        parts = A.parse_container(c)
+        assert bool(parts["header"].kind & 0x200) == wide and parts["header"].nblocks == 5
+        for b in range(5):
+            s, info, est, eoff = ol.oracle_encode(ol.FOLD, 1, data[b * 4096:(b + 1) * 4096], ckpt_interval=1024)
+            k = est.shape[0]
+            assert np.array_equal(parts["streams"][b], s)
+            assert np.array_equal(parts["ckpt_state"][b][:k], est) and np.array_equal(parts["ckpt_off"][b][:k], eoff)
+    v2 = cp.build_container(ol.FOLD, 1, data, 4096, 1024).copy()
+    v2[5] = ord("2")
+    with pytest.raises(A.AnsxError):
+        A.parse_container(v2)
+
+
 def test_init_without_device_fails_loudly(A):
     """No GPU in the CPU container: the product must refuse, not fall back."""
     import torch

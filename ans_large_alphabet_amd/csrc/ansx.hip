@@ -1309,9 +1309,15 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if ((rc = ensure(c, c->plain, in_bytes + 64))) return rc;
         HIPCHK(c, hipMemsetAsync(c->plain.p, 0, 16, s));
         HIPCHK(c, hipMemcpyAsync((u8*)c->plain.p + 16, d_in, in_bytes, hipMemcpyDeviceToDevice, s));
+        // ONE host round trip: the first 16 bytes and, for ANSrfold, the 8 bytes behind a most-frequent table (where the
+        // prelude starts if the block was reordered) are requested together
         size_t peek = in_bytes < 16 ? in_bytes : 16;
         u8* hp = (u8*)c->h_pin + 64;
+        u8* hp2 = hp + 16;
+        const size_t pos_rf = 4 + 4 * (size_t)T;
+        const bool have_rf = P.g.kind == ANSX_RFOLD && pos_rf + 8 <= in_bytes;
         HIPCHK(c, hipMemcpyAsync(hp, d_in, peek, hipMemcpyDeviceToHost, s));
+        if (have_rf) HIPCHK(c, hipMemcpyAsync(hp2, d_in + pos_rf, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         size_t pos = 0;
         if (P.g.kind == ANSX_RFOLD) {
@@ -1321,8 +1327,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
             pos = 4 + (flag ? 4 * (size_t)T : 0);
             if (pos + 8 > in_bytes) return ANSX_ERR_FORMAT;
             if (flag) {
-                HIPCHK(c, hipMemcpyAsync(hp, d_in + pos, 8, hipMemcpyDeviceToHost, s));
-                HIPCHK(c, hipStreamSynchronize(s));
+                hp = hp2;
                 pos = 0;
             }
         }
@@ -1337,10 +1342,12 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if (ms >= P.NSP || lg > 31) return ANSX_ERR_FORMAT;
         maxM = 1u << lg;
         max_ns = ms + 1;
-        u64 hb[2] = { 0, (u64)in_bytes };
+        // (the two index entries of the one block go up from pinned memory: no wait -- the page is next written by
+        // this call's final read-back, which the stream orders behind this copy)
+        u64* hb = (u64*)((u8*)c->h_pin + 64 + 32);
+        hb[0] = 0, hb[1] = (u64)in_bytes;
         u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
         HIPCHK(c, hipMemcpyAsync(boff_ws, hb, 16, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));  // hb is a stack buffer
         cont = (const u8*)c->plain.p;
         boff = boff_ws;
         payload_off = 16;

@@ -17,7 +17,7 @@ SINGLE_STREAM = 0xFFFFFFFF
 NO_CHECKPOINTS = 0xFFFFFFFF
 DEFAULT_BLOCK_INTS = 16384
 DEFAULT_CKPT_INTERVAL = 1024
-MAX_FIDELITY = 5
+MAX_FIDELITY = 7
 GEN_UNIFORM, GEN_GEOMETRIC, GEN_ZIPF = 0, 1, 2
 
 EXPORTS = [

@@ -52,6 +52,7 @@ struct ansx_ctx {
     std::vector<ProfRec> recs;
     std::map<std::string, std::pair<double, u64>> acc;
     std::vector<std::string> order;
+    DevBuf pre_work;  // f = 6, 7: off[] and bit buffer of the generic prelude writer
     DevBuf hist, hterm, sortF, sortSym, attS, prevS, attMeta, blk, table, tab32, scratch, misc, mapped, mostfreq,
         stage_in, stage_out, dec_s2s, dec_cum, dec_info, plain, rf_tmp, log2lut, pa_alpha, pa_info, pairs, lg2i, sizes, nearlist, force;
     u32* h_pin = nullptr;  // pinned: [0..3] gflags, [4..7] result (2 x u64), [8..] header scratch
@@ -294,7 +295,7 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
     ansx_blk* blk, u32* gflags, hipStream_t s, u32 opt_slots = 0)
 {
     const u32 T = fold_T(g.f);
-    if (g.block_ints > 16384u) {
+    if (g.block_ints > 16384u || T > 4096u) {  // (T > 4096: f = 6, 7 -- the selection buffer alone is 64 / 128 KB)
         // large blocks (incl. whole-list single-stream mode): hash table in HBM
         u32 slots = 2;
         while ((u64)slots < 2ull * g.block_ints && slots < (1u << 31)) slots <<= 1;
@@ -502,22 +503,37 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     }
     // (fast path: H is a tree sum in registers, no LDS row of terms)
     const size_t hist_lds = !h_in_hist ? (size_t)NSP * 4 : (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (fast ? 0 : (size_t)NSP * 8 + 80);
-    LAUNCH(c, "k_fold_hist", k_fold_hist, (size_t)NB * cpb, 256, hist_lds, s, src, g, chunk, cpb, NSP, hist, hterm,
-        (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
+    if (NSP > 16384u) {  // f = 6, 7: 16-bit counters, two per LDS word (a chunk holds at most 16384 values)
+        const size_t packed_lds = (size_t)NSP * 2;
+        if (packed_lds > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_fold_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)packed_lds));
+        LAUNCH(c, "k_fold_hist", k_fold_hist<true>, (size_t)NB * cpb, 256, packed_lds, s, src, g, chunk, cpb, NSP, hist, hterm,
+            0u, blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
+    } else {
+        if (hist_lds > 48 * 1024)
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_fold_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+        LAUNCH(c, "k_fold_hist", k_fold_hist<false>, (size_t)NB * cpb, 256, hist_lds, s, src, g, chunk, cpb, NSP, hist, hterm,
+            (h_in_hist ? 1u : 0u) | (fast ? 2u : 0u), blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
+    }
     // K2.  "big" symbols have freq >= ANSX_VMAX, so a block holds at most block_ints/ANSX_VMAX
     const u32 nbig_cap = (u32)std::min<size_t>(NSP, (size_t)g.block_ints / ANSX_VMAX + 2);
     // (optimistic calls with whole-block histograms: the staged row is as long as the alphabet hint, see the kernel)
     const u32 sort_cap = (optimistic && h_deferred) ? std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 7u) & ~7u)) : NSP;
     const bool sort16 = g.block_ints <= 65535u;  // (a count fits 16 bits: half the staged row)
-    const size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)sort_cap * (sort16 ? 2 : 4) + (h_deferred ? 0 : 512 * 8);
+    size_t k2a_lds = (size_t)nbig_cap * 8 + (size_t)sort_cap * (sort16 ? 2 : 4) + (h_deferred ? 0 : 512 * 8);
+    const bool sort_staged = k2a_lds <= 150 * 1024;  // (f = 6, 7 with 32-bit counts: the row stays in HBM)
+    if (!sort_staged) k2a_lds = (size_t)nbig_cap * 8 + (h_deferred ? 0 : 512 * 8);
     if (k2a_lds > 32 * 1024) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sort_entropy<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2a_lds));
     }
-    if ((size_t)NSP * 8 + 64 > 48 * 1024)
+    if ((size_t)NSP * 8 + 64 > 48 * 1024 && (size_t)NSP * 8 + 64 <= 150 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)k_write_prelude<0>,
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NSP * 8 + 64)));
-    if (sort16)
+    if (!sort_staged)
+        LAUNCH(c, "k_sort_entropy", (k_sort_entropy<u32, false>), NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
+            (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
+    else if (sort16)
         LAUNCH(c, "k_sort_entropy", k_sort_entropy<u16>, NB, 64, k2a_lds, s, g, NSP, nbig_cap, h_deferred ? 1u : 0u, hist,
             (u32*)c->sortF.p, (u16*)c->sortSym.p, blk, sort_cap, fast ? (uint2*)c->pairs.p : (uint2*)nullptr, gflags);
     else
@@ -625,9 +641,15 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq, hints, pre_cap, geo);
     } else {
+        if ((size_t)NSP * 8 + 64 > 150 * 1024) {  // f = 6, 7: the writer's two arrays in HBM
+            if ((rc = ensure(c, c->pre_work, (size_t)NB * (2 * (size_t)NSP + 16) * 4))) return rc;
+            LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, 64, s, g, NSP,
+                (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr, (u32*)c->pre_work.p);
+        } else
         LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr);
+            (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr, (u32*)nullptr);
     }
     // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
     // alphabet / frame actually produced, read back above).
@@ -1610,7 +1632,7 @@ void ansx_destroy(ansx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+    DevBuf* bufs[] = { &c->pre_work, &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
         &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes, &c->nearlist, &c->force };
     for (DevBuf* b : bufs)
@@ -1948,7 +1970,7 @@ int ansx_profile_get(ansx_ctx* c, ansx_kernel_time* out, int max_entries, int* c
 size_t ansx_workspace_bytes(const ansx_ctx* c)
 {
     if (!c) return 0;
-    const DevBuf* bufs[] = { &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
+    const DevBuf* bufs[] = { &c->pre_work, &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
         &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->pa_alpha, &c->pa_info, &c->pairs, &c->sizes };
     size_t t = 0;

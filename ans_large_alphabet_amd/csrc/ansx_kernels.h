@@ -116,6 +116,9 @@ __device__ __forceinline__ uint4 ld16_stream(const uint4* p)
     const ansx_u32x4 v = __builtin_nontemporal_load((const ansx_u32x4*)p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+// PACKED (alphabets above 16 Ki slots, f = 6, 7): one copy of 16-bit counters, two symbols per LDS word -- a chunk
+// holds at most 16384 values, so a count cannot carry into its neighbour -- NSP * 2 bytes of LDS instead of NSP * 4.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, ansx_geo g,
     u32 chunk, u32 cpb, u32 NSP, u32* __restrict__ hist, double* __restrict__ hterm, u32 sum_mode,
     ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
@@ -139,7 +142,11 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
     // them; copies are ANSX_HCOPY_PAD words apart modulo the 32 banks so the same symbol's four
     // counters sit in different banks.  Layout: [4][NSP + pad] u32 | [NSP + 8] f64 terms | max word.
     const u32 cstride = sum_here ? NSP + ANSX_HCOPY_PAD : 0;
-    const u32 hwords = sum_here ? 4 * cstride : NSP;
+    const u32 hwords = sum_here ? 4 * cstride : (PACKED ? NSP / 2 : NSP);
+    auto hcount = [&](u32 sy) -> u32 {  // symbol sy's count in (copy 0 of) the LDS histogram
+        if constexpr (PACKED) return (lds_hist[sy >> 1] >> (16u * (sy & 1u))) & 0xFFFFu;
+        else return lds_hist[sy];
+    };
     for (u32 s = tid; s < hwords; s += 256) lds_hist[s] = 0;
     u32* const aux = lds_hist + hwords;  // terms (f64, 8-byte aligned: hwords is even), then the max word
     if (sum_here && !tree_sum && tid < 17) aux[2 * NSP + tid] = 0;  // 8 pad terms + the max word (see below)
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         // (fold / msb maps keep every 32-bit value inside the symbol array; ANSint's identity map does not: a value
         // at or above value_limit = NSP is a domain error, counted as symbol 0 so that nothing is written out of range)
         if (ident) s = s < NSP ? s : 0u;
-        atomicAdd(&my_hist[s], 1u);
+        if constexpr (PACKED) atomicAdd(&my_hist[s >> 1], 1u << (16u * (s & 1u)));
+        else atomicAdd(&my_hist[s], 1u);
         lmax = s > lmax ? s : lmax;
     };
     u32 done = 0;
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
             return p * ansx_log2_portable(p);
         };
         for (u32 s = tid; s < NSP; s += 256) {
-            u32 fr = lds_hist[s];
+            u32 fr = hcount(s);
             if (sum_here) fr += lds_hist[cstride + s] + lds_hist[2 * cstride + s] + lds_hist[3 * cstride + s];
             h[s] = fr;
             const double t = term(fr);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
         }
     } else {
         for (u32 s = tid; s < NSP; s += 256) {
-            u32 v = lds_hist[s];
+            u32 v = hcount(s);
             if (v) atomicAdd(&h[s], v);
         }
     }
@@ -306,7 +314,8 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // the divisor of that symbol's scale_freqs step (ans_util.hpp:83), so that k_candidates can prepare its reciprocal.
 // HT: type of the staged row -- u16 for blocks of at most 65535 values (a count cannot exceed the block length): half
 // the dynamic LDS, i.e. more blocks per CU for this occupancy-bound kernel.
-template <typename HT>
+// STAGED = false (alphabets whose row does not fit the LDS, f = 6, 7): the three passes read the row from HBM instead.
+template <typename HT, bool STAGED = true>
 __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nbig_cap, u32 h_deferred,
     const u32* __restrict__ hist, u32* __restrict__ sortF, u16* __restrict__ sortSym,
     ansx_blk* __restrict__ blk, u32 cap, uint2* __restrict__ pairs, u32* __restrict__ gflags)
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     __shared__ u32 sh_nbig;
     u64* big_keys = lds_k2a;
     HT* hrow = (HT*)(lds_k2a + nbig_cap);  // [cap] this block's histogram row
-    double* terms = (double*)(hrow + cap);   // [512], only allocated when the entropy is summed here
+    double* terms = (double*)(hrow + (STAGED ? cap : 0u));   // [512], only allocated when the entropy is summed here
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const u32* h = hist + (u64)b * NSP;
@@ -330,7 +339,11 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
 #pragma unroll
     for (u32 r = 0; r < SORT_PRE; r++) hp[r] = r * 64 + lane < NSP ? h[r * 64 + lane] : 0u;
     const u32 ns = blk[b].max_sym + 1;
-    if (ns > cap) {
+    auto hget = [&](u32 sy) -> u32 {
+        if constexpr (STAGED) return hrow[sy];
+        else return h[sy];
+    };
+    if (STAGED && ns > cap) {
         // the block outgrew the alphabet hint this (optimistic) call is sized for: no model, no stream -- said
         // explicitly, so that the repeat does not hang on what the later kernels make of an untouched block
         if (lane == 0) {
@@ -343,10 +356,12 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     u32* oF = sortF + (u64)b * NSP;
     u16* oS = sortSym + (u64)b * NSP;
     uint2* oP = pairs ? pairs + (u64)b * NSP : nullptr;
+    if constexpr (STAGED) {
 #pragma unroll
-    for (u32 r = 0; r < SORT_PRE; r++)
-        if (r * 64 + lane < ns) hrow[r * 64 + lane] = (HT)hp[r];
-    for (u32 s = SORT_PRE * 64 + lane; s < ns; s += 64) hrow[s] = (HT)h[s];
+        for (u32 r = 0; r < SORT_PRE; r++)
+            if (r * 64 + lane < ns) hrow[r * 64 + lane] = (HT)hp[r];
+        for (u32 s = SORT_PRE * 64 + lane; s < ns; s += 64) hrow[s] = (HT)h[s];
+    }
     for (u32 v = lane; v < ANSX_VMAX; v += 64) cnt[v] = 0;
     for (u32 v = lane; v < ANSX_MASKV; v += 64) vmask[v] = 0;
     if (lane == 0) sh_nbig = 0;
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     u64 total = 0;
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
-        const u32 fr = s < ns ? hrow[s] : 0u;
+        const u32 fr = s < ns ? hget(s) : 0u;
         if (fr) {
             sigma++;
             total += fr;
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
     // pass 3: stable placement, 64 symbols at a time in index order
     for (u32 s0 = 0; s0 < ns; s0 += 64) {
         const u32 s = s0 + lane;
-        const u32 fr = s < ns ? hrow[s] : 0u;
+        const u32 fr = s < ns ? hget(s) : 0u;
         const bool small = fr != 0 && fr < ANSX_VMAX;
         // a frequency value that occurs once in the whole block needs no ranking: its symbol goes
         // to the start of its bin (this covers nearly all "hot" symbols, whose values are all
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(64) void k_sort_entropy(ansx_geo g, u32 NSP, u32 nb
         wave_lds_sync();
         for (u32 u = lane; u < 512; u += 64) {
             u32 i = base + u;
-            u32 fr = i < ns ? hrow[i] : 0u;
+            u32 fr = i < ns ? hget(i) : 0u;
             // an absent symbol adds p*log2(1) = +0.0: the sum (never -0.0) is unchanged
             double p = fr ? (double)fr / nd : 0.0;
             double q = fr ? p : 1.0;
@@ -1071,6 +1086,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
             ansx_code c = interp_item<W>(inc, ns, u, i, geo_row);
             off[c.rank] = c.len;
         }
+        __threadfence_block();  // (off[] and the bit buffer may live in HBM on this path)
     }
     __syncthreads();
     // exclusive scan of off[0..ns)
@@ -1087,6 +1103,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
     }
     const u32 nwords = (total_bits + 31) >> 5;
     for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
+    if (!SMALL) __threadfence_block();
     __syncthreads();
     if (!PA && hints != nullptr && tid < 8) {
         // Parse hints for the container index: where the decoder may enter this code in parallel.  The code
@@ -1128,6 +1145,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
         for (u32 i = tid; i < ns; i += 256) place(interp_item<W>(inc, ns, u, i, geo_row));
+        __threadfence_block();
     }
     __syncthreads();
     const u32 nbytes = nwords * 4;
@@ -1183,8 +1201,10 @@ template <int IPT>
 __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32* __restrict__ incbuf,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
-    u32* __restrict__ hints, u32 cap, const uint2* __restrict__ geo)
+    u32* __restrict__ hints, u32 cap, const uint2* __restrict__ geo, u32* __restrict__ g_work = nullptr)
 {
+    // g_work (IPT == 0 only; alphabets above 16 Ki slots, whose two arrays do not fit the LDS): 2 cap + 16 words of
+    // HBM per block for off[] and the bit buffer instead.
     // cap = words per LDS array: NSP, or on an optimistic call the alphabet hint the whole call is sized for (a
     // 2300-symbol alphabet then takes 28 KB instead of the 48 KB of its 4096 slots: 5 instead of 3 workgroups per
     // CU); a block above it writes nothing -- the call is repeated anyway (ANSX_G_MAXNSYMS > hint).
@@ -1213,8 +1233,8 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         if (tid == 0) B->prelude_bytes = 0;
         return;
     }
-    u32* off = lds32;         // [ns]
-    u32* bits = lds32 + cap;  // bit buffer
+    u32* off = (!SMALL && g_work != nullptr) ? g_work + (u64)b * (2 * (u64)cap + 16) : lds32;  // [ns]
+    u32* bits = off + cap;    // bit buffer
     u32* inc = SMALL ? lds32 + 2 * cap : incbuf + (u64)b * NSP;
     if (SMALL) {
 #pragma unroll

@@ -76,11 +76,15 @@ int main(int argc, char const* argv[])
             run<ANSfoldGPU<3>>(inputs);
             run<ANSfoldGPU<4>>(inputs);
             run<ANSfoldGPU<5>>(inputs);
+            run<ANSfoldGPU<6>>(inputs);  // fold_effectiveness.cpp:132-139 sweeps 1..8; 8 is unsound upstream
+            run<ANSfoldGPU<7>>(inputs);
             run<ANSrfoldGPU<1>>(inputs);
             run<ANSrfoldGPU<2>>(inputs);
             run<ANSrfoldGPU<3>>(inputs);
             run<ANSrfoldGPU<4>>(inputs);
             run<ANSrfoldGPU<5>>(inputs);
+            run<ANSrfoldGPU<6>>(inputs);
+            run<ANSrfoldGPU<7>>(inputs);
         } else {
             run<ANSmsbGPUStream>(inputs);
             run<ANSfoldGPUStream<1>>(inputs);

@@ -75,10 +75,10 @@ typedef enum {
 #define ANSX_SINGLE_STREAM 0xFFFFFFFFu /* opts.block_ints: one plain reference stream          */
 #define ANSX_NO_CHECKPOINTS 0xFFFFFFFFu /* opts.ckpt_interval: no decoder restart points        */
 /* Largest fidelity accepted.  The reference instantiates ANSfold<1..8> (methods.hpp:529-567) but is only
- * sound up to 7 (rfold<8> truncates symbols to u16, fold<8> can hit the u16 bail-out); here the
- * per-block model state of a block (2^(f+9) symbol slots) must fit one CU's 160 KB of LDS, which holds up
- * to f = 5 (16384 slots).  f = 6, 7 are rejected with ANSX_ERR_ARG (containers: ANSX_ERR_FORMAT). */
-#define ANSX_MAX_FIDELITY 5
+ * sound up to 7 (rfold<8> truncates symbols to u16, fold<8> can hit the u16 bail-out).  f <= 5
+ * (up to 16384 symbol slots) keeps a block's model in a CU's LDS; f = 6, 7 (32 Ki / 64 Ki slots) run the same
+ * stages with their per-block arrays in HBM -- correct and bit-identical, not tuned.  f = 8: ANSX_ERR_ARG. */
+#define ANSX_MAX_FIDELITY 7
 #define ANSX_DEFAULT_BLOCK_INTS 16384u
 #define ANSX_DEFAULT_CKPT_INTERVAL 1024u
 

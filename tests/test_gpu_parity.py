@@ -126,14 +126,39 @@ def test_even_fidelities_match_oracle(A, ctx, kind, f):
         assert np.array_equal(codec.decode(cont, n), data), fam
 
 
-def test_fidelities_above_the_lds_limit_are_rejected(A, ctx):
-    """f = 6, 7 need more model state per block than a CU's LDS holds: ANSX_ERR_ARG, not a HIP error."""
+def test_fidelity_8_is_rejected(A, ctx):
+    """f = 8 is unsound in the reference itself: ANSX_ERR_ARG, not a HIP error."""
     data = ol.gen_inputs("uniform20", 5000, seed=3)
-    for f in (6, 7, 8):
-        for cls in (A.ANSfold, A.ANSrfold):
-            with pytest.raises(A.AnsxError) as ei:
-                cls(f, ctx=ctx).encode(data)
-            assert ei.value.status == 1
+    for cls in (A.ANSfold, A.ANSrfold):
+        with pytest.raises(A.AnsxError) as ei:
+            cls(8, ctx=ctx).encode(data)
+        assert ei.value.status == 1
+
+
+@pytest.mark.parametrize("kind", [ol.FOLD, ol.RFOLD])
+@pytest.mark.parametrize("f", [6, 7])
+def test_fidelities_6_and_7(A, ctx, kind, f):
+    """Alphabets of 32 Ki / 64 Ki slots (methods.hpp:529-567 instantiates them): the per-block arrays of the histogram,
+    sort, prelude-writer and decode-table stages live in HBM there.  Every block stream, restart point and header field
+    against the oracle; round trip; ragged sizes; single-stream mode = the reference's bytes."""
+    for fam, n, block, ck in (("zipf24", 70001, 16384, 1024), ("uniform20", 40000, 8192, 2048), ("sparse_large", 33000, 16384, 0),
+                              ("zipf20s1.2", 9999, 4096, 512), ("distinct", 20000, 16384, 1024), ("boundaries", 5000, 4096, 1024),
+                              ("zipf24", 150000, 65536, 4096)):
+        data = ol.gen_inputs(fam, n, seed=13 * f + 1)
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ck if ck else A.NO_CHECKPOINTS)
+        cont = codec.encode(data)
+        check_container(A, cont, data, kind, f, block, ck)
+        assert np.array_equal(codec.decode(cont, n), data), (fam, n)
+    data = ol.gen_inputs("zipf24", 30011, seed=f)
+    if kind == ol.RFOLD:
+        data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+    one = codec_for(A, ctx, kind, f, block_ints=A.SINGLE_STREAM)
+    stream = one.encode(data)
+    exp = ol.oracle_encode(kind, f, data)[0]
+    assert np.array_equal(stream, exp)
+    assert np.array_equal(one.decode(exp, data.size), data)
 
 
 @pytest.mark.parametrize("f", [1, 3, 5])
@@ -250,7 +275,7 @@ def test_golden_fixtures_single_stream(A, ctx):
         assert np.array_equal(codec.decode(ref_stream, e["n"]), data)
 
 
-@pytest.mark.parametrize("fixture", ["large.json", "f24.json"])
+@pytest.mark.parametrize("fixture", ["large.json", "f24.json", "f67.json"])
 def test_golden_fixtures_large(A, ctx, fixture):
     with open(os.path.join(GOLD, fixture)) as fh:
         gold = json.load(fh)

@@ -101,7 +101,7 @@ def test_golden_small():
         assert np.array_equal(ol.oracle_decode(KIND[e["kind"]], e["f"], ref_stream, e["n"]), data), tag
 
 
-@pytest.mark.parametrize("fixture", ["large.json", "f24.json"])
+@pytest.mark.parametrize("fixture", ["large.json", "f24.json", "f67.json"])
 def test_golden_large(fixture):
     gold = _load(fixture)
     for e in gold:

@@ -11,7 +11,8 @@ Round 2 (rewritten encoder main loop, trimmed decoder step, prefetching decoder 
 (seed 11, 300 s) and 107 196 (seed 21, 420 s), 0 failures, 0 near-threshold frame-size decisions; end of round 2 (parser / candidate-
 kernel changes, hint-sized ANSrfold hash tables with their overflow-and-repeat path): 88 959 iterations (seed 31, 360 s), 0 failures.
 Round 3 (fast model path, container v3, DPP scans; plain ANSint and the restart points of every checked block added to the
-cases): 90 885 iterations (seed 41, 400 s) and, with the final kernels, 54 106 (seed 51, 240 s), 0 failures, 0 near-threshold decisions.
+cases): 90 885 iterations (seed 41, 400 s) and, with the final kernels, 54 106 (seed 51, 240 s), 0 failures, 0 near-threshold decisions;
+SOAK_F67=1 (fidelities 5..7 only: the HBM-backed large-alphabet stages): 33 637 iterations (seed 61, 300 s), 0 failures.
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,7 +38,9 @@ blocks = [(16384, 1024), (16384, 256), (4096, 512), (65536, 1024), (8192, 2048),
 t0 = time.time(); it = 0; fails = 0; near = 0
 while time.time() - t0 < budget:
     it += 1
-    kind, f = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0), (ol.INT, 0)][int(rng.integers(0, 8))]
+    CODECS = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0), (ol.INT, 0)]
+    if os.environ.get("SOAK_F67"): CODECS = [(ol.FOLD, 6), (ol.FOLD, 7), (ol.RFOLD, 6), (ol.RFOLD, 7), (ol.FOLD, 5), (ol.RFOLD, 5)]  # the HBM-backed large-alphabet stages
+    kind, f = CODECS[int(rng.integers(0, len(CODECS)))]
     block, ckpt = blocks[int(rng.integers(0, len(blocks)))]
     n = int(rng.integers(1, 1 << int(rng.integers(4, 22))))
     data = gen(kind, n)

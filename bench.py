@@ -449,6 +449,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs rows (N = 1)")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the host-buffer API row (its calls run on a 64 Mi-int sample: under rocprofv3 --stats they "
+                         "would pull the per-kernel averages away from the timed steps')")
     ap.add_argument("--no-frontier", action="store_true", help="skip the block size / restart interval frontier rows (N = 1)")
     ap.add_argument("--gather-root", default="auto", choices=["auto", "fixed", "rotate"],
                     help="N > 1: root of the per-step container gather: rank k mod N of step k (rotate: spreads the "
@@ -708,7 +711,7 @@ def main():
         sample = d_in[:m].cpu().numpy().view("uint32")
         cpu = cpu_baseline(sample, kind, args.fidelity, block_ints)
         cpu_all = all_cores_baseline(sample, kind, args.fidelity, block_ints)
-        host_api = host_buffer_rates(codec, sample[:min(m, 64 * (1 << 20))])
+        host_api = None if args.no_host_api else host_buffer_rates(codec, sample[:min(m, 64 * (1 << 20))])
 
     # ---- the other single-GPU BASELINE configs, a few steps each (N = 1 only)
     extra = None

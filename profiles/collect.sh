@@ -18,7 +18,7 @@ HB=$!
 trap "kill $HB 2>/dev/null" EXIT
 python3 -c 'import torch; torch.zeros(1).cuda()' 2>/dev/null   # page the image in
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
-    python3 bench.py --steps 10 --warmup 2 --no-extra $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
+    python3 bench.py --steps 10 --warmup 2 --no-extra --no-host-api $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- \
     python3 bench.py --steps 1 --warmup 0 --no-cpu --no-profile --no-extra $BENCH_ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- \

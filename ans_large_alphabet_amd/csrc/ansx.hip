@@ -503,7 +503,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     }
     // (fast path: H is a tree sum in registers, no LDS row of terms)
     const size_t hist_lds = !h_in_hist ? (size_t)NSP * 4 : (size_t)4 * (NSP + ANSX_HCOPY_PAD) * 4 + (fast ? 0 : (size_t)NSP * 8 + 80);
-    if (NSP > 16384u) {  // f = 6, 7: 16-bit counters, two per LDS word (a chunk holds at most 16384 values)
+    if (NSP >= 8192u) {  // f >= 4: 16-bit counters, two per LDS word (a chunk holds at most 16384 values): half the LDS, twice the workgroups per CU
         const size_t packed_lds = (size_t)NSP * 2;
         if (packed_lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_fold_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)packed_lds));
@@ -641,15 +641,16 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq, hints, pre_cap, geo);
     } else {
-        if ((size_t)NSP * 8 + 64 > 150 * 1024) {  // f = 6, 7: the writer's two arrays in HBM
-            if ((rc = ensure(c, c->pre_work, (size_t)NB * (2 * (size_t)NSP + 16) * 4))) return rc;
+        const size_t gen_lds = (size_t)pre_cap * 8 + 64;  // (as long as the call's largest alphabet, not as its slot count: workgroups per CU)
+        if (gen_lds > 150 * 1024) {  // f = 6, 7: the writer's two arrays in HBM
+            if ((rc = ensure(c, c->pre_work, (size_t)NB * (2 * (size_t)pre_cap + 16) * 4))) return rc;
             LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, 64, s, g, NSP,
                 (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr, (u32*)c->pre_work.p);
+                (u64)scr_stride, mostfreq, hints, pre_cap, (const uint2*)nullptr, (u32*)c->pre_work.p);
         } else
-        LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, (size_t)NSP * 8 + 64, s, g, NSP,
+        LAUNCH(c, "k_write_prelude", (k_write_prelude<0>), NB, 256, gen_lds, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, mostfreq, hints, NSP, (const uint2*)nullptr, (u32*)nullptr);
+            (u64)scr_stride, mostfreq, hints, pre_cap, (const uint2*)nullptr, (u32*)nullptr);
     }
     // K5.  The encoder keeps its 16 per-wave tables in LDS when they fit (sized from the largest
     // alphabet / frame actually produced, read back above).

@@ -36,7 +36,7 @@ class Opts(C.Structure):
 
 
 class ContainerHeader(C.Structure):
-    _fields_ = [("magic", C.c_uint8 * 8), ("kind", C.c_uint32), ("fidelity", C.c_uint32),
+    _fields_ = [("magic", C.c_uint8 * 6), ("max_present_m1", C.c_uint16), ("kind", C.c_uint32), ("fidelity", C.c_uint32),
                 ("n", C.c_uint64), ("block_ints", C.c_uint32), ("ckpt_interval", C.c_uint32),
                 ("nblocks", C.c_uint32), ("max_log2_frame", C.c_uint32), ("max_nsyms", C.c_uint32),
                 ("ckpts_per_block", C.c_uint32), ("payload_bytes", C.c_uint64),

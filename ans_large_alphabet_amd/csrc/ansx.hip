@@ -1117,8 +1117,10 @@ int encode_dev(ansx_ctx* c, const Plan& P0, const u32* d_in, u8* d_out, size_t c
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info, const u32* hints)
+    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info, const u32* hints, u32 max_ep)
 {
+    // max_ep: the header's bound on the symbols PRESENT in a block (<= max_ns, its bound on their indices): the
+    // rank / select decoder keeps one 8-byte entry per present symbol, so this -- not max_ns -- sizes its LDS
     const u32 T = fold_T(g.f);
     int rc;
     if ((rc = ensure(c, c->dec_cum, (size_t)g.nblocks * (NSP + 8) * 4))) return rc;
@@ -1174,7 +1176,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     const size_t want_stream = rup((size_t)max_block_bytes + 32, 16);
     const size_t LDS_LIMIT = 150 * 1024;
     // normal path: rank/select tables (frames up to 2^16), staged stream while >= 3 WGs/CU still fit
-    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16) + ANSX_DEC_SCRATCH;
+    const size_t rs_tables = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ep * 4, 16) + ANSX_DEC_SCRATCH;
     if (maxM <= 65536u && rs_tables <= LDS_LIMIT && !c->dbg.decode_table) {
         // per-quad stream rings when every segment of a full block has the same length; the (at
         // most one) partial block of the container then reads its stream straight from HBM
@@ -1197,7 +1199,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LAUNCH(c, "k_decode", (k_decode_rank<RF, true>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
-                ck_state, ck_off, payload_off, d_out, maxM, max_ns, (u64)cont_bytes, (const u32*)c->dec_cum.p,
+                ck_state, ck_off, payload_off, d_out, maxM, max_ep, (u64)cont_bytes, (const u32*)c->dec_cum.p,
                 (const uint4*)c->dec_info.p, gflags);
             return ANSX_OK;
         }
@@ -1211,7 +1213,7 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
             HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LAUNCH(c, "k_decode", (k_decode_rank<RF, false>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
-            ck_off, payload_off, d_out, maxM, max_ns, (u64)stream_cap, (const u32*)c->dec_cum.p,
+            ck_off, payload_off, d_out, maxM, max_ep, (u64)stream_cap, (const u32*)c->dec_cum.p,
             (const uint4*)c->dec_info.p, gflags);
         return ANSX_OK;
     }
@@ -1296,8 +1298,8 @@ int parse_header(const u8* h, size_t bytes, ansx_container_header* out)
     if (bytes < sizeof(ansx_container_header)) return ANSX_ERR_FORMAT;
     ansx_container_header H;
     memcpy(&H, h, sizeof(H));
-    static const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
-    if (memcmp(H.magic, magic, 8) != 0) return ANSX_ERR_FORMAT;
+    static const char magic[6] = { 'A', 'N', 'S', 'X', 'v', '3' };
+    if (memcmp(H.magic, magic, 6) != 0) return ANSX_ERR_FORMAT;
     const u32 k = H.kind & 0xFFu;  // bit 8: per-block alphabet compaction, bit 9: wide restart points
     if ((H.kind & ~0x3FFu) || k > 3 || H.n == 0 || H.block_ints == 0) return ANSX_ERR_FORMAT;
     if ((k == ANSX_MSB || k == ANSX_INT) ? H.fidelity != 0 : (H.fidelity < 1 || H.fidelity > ANSX_MAX_FIDELITY)) return ANSX_ERR_FORMAT;
@@ -1319,6 +1321,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     const u32 f = P.g.f;
     const u32 T = fold_T(f);
     u32 maxM, max_ns, max_block_bytes;
+    u32 max_ep = 0;  // bound on the symbols present in a block (0: as many as max_ns)
     const u8* cont;
     const u64* boff;
     const u64* ck_state = nullptr;
@@ -1414,6 +1417,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         if (H.max_log2_frame > 31 || (H.max_nsyms == 0 && !P.g.pa) || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
         maxM = 1u << H.max_log2_frame;
         max_ns = H.max_nsyms ? H.max_nsyms : 1u;
+        max_ep = std::min<u32>(max_ns, (u32)H.max_present_m1 + 1u);
         cont = d_in;
         boff = (const u64*)(d_in + P.lay.index_off);
         ck_state = (const u64*)(d_in + P.lay.ckstate_off);
@@ -1423,7 +1427,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         P.g.payload_bytes = H.payload_bytes;  // every parser validates the two index entries of its own block (index_entry_ok)
         // The ring decoder needs nothing else from the index: no validation kernel, no read-back.  The staged /
         // straight-from-HBM forms size their LDS from the largest block stream, which only the index knows.
-        const size_t rs_probe = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ns * 4, 16) + ANSX_DEC_SCRATCH;
+        const size_t rs_probe = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 8, 16) + 2 * rup((size_t)max_ep * 4, 16) + ANSX_DEC_SCRATCH;
         const bool ring_certain = !P.g.pa && maxM <= 65536u && P.g.ckpt != 0 && P.g.block_ints % P.g.ckpt == 0 && P.g.ckpt % 4 == 0
             && c->dbg.decode_mode != 2 && !c->dbg.decode_table
             && rs_probe + (size_t)(std::min<u32>(256u, (u32)rup((size_t)geo_nseg(P.g.block_ints, P.g.ckpt) * 4, 64)) / 4) * ANSX_RING_STRIDE + 16 <= 60 * 1024;
@@ -1454,10 +1458,10 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints, max_ep ? max_ep : max_ns);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints, max_ep ? max_ep : max_ns);
     if (rc) return rc;
     if (P.g.pa)
         LAUNCH(c, "k_pa_unmap", k_pa_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, pa_info, d_out, gflags);
@@ -1833,6 +1837,11 @@ int ansx_merge_containers_dev(ansx_ctx* c, const uint8_t* const* d_parts, const 
     M.nblocks = (u32)nblocks;
     M.max_log2_frame = maxlg;
     M.max_nsyms = maxns;
+    {
+        u32 mp = 0;
+        for (int i = 0; i < nparts; i++) mp = std::max<u32>(mp, H[(size_t)i].max_present_m1);
+        M.max_present_m1 = (u16)mp;
+    }
     M.payload_bytes = pay;
     M.payload_offset = P.lay.payload_off;
     memcpy(hp, &M, 64);

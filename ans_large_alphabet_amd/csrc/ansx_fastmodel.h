@@ -518,6 +518,8 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
             atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXSIGMA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sigma)
+            atomicMax(&gflags[ANSX_G_MAXSIGMA], sigma);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)chosen)
             atomicMax(&gflags[ANSX_G_MAXT], (u32)chosen);
     }

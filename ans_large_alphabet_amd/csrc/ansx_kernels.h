@@ -68,7 +68,9 @@ enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
     // (words 4, 5 hold the 64-bit payload size)
     ANSX_G_NEAR = 6,    // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
     ANSX_G_RFDIST = 7,  // rfold: the most distinct values any block of the call had (sizes the next call's hash tables)
-    ANSX_G_MAXT = 8 };  // largest chosen candidate index t (frame = M0 * 2^t) of the call: lanes per block of k_candidates
+    ANSX_G_MAXT = 8,    // largest chosen candidate index t (frame = M0 * 2^t) of the call: lanes per block of k_candidates
+    ANSX_G_MAXSIGMA = 9 };  // most symbols PRESENT in any block (<= its alphabet size): goes into the container header and
+                            // sizes the decoder's per-present-symbol table
 
 // The one step of the path whose parity with the reference is empirical rather than by construction:
 // log2 is libm's there and ansx_log2_portable here (<= 1 ulp apart), so the decision XH < H * 1.001
@@ -908,6 +910,8 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
             atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
             atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXSIGMA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B->sigma)
+            atomicMax(&gflags[ANSX_G_MAXSIGMA], B->sigma);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u32)chosen)
             atomicMax(&gflags[ANSX_G_MAXT], (u32)chosen);
     }
@@ -2153,7 +2157,11 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     // ansx_container_header, little endian (include/ansx.h)
     const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
-    for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
+    for (int i = 0; i < 6; i++) out[i] = (u8)magic[i];
+    {
+        const u32 ms = gflags[ANSX_G_MAXSIGMA];  // bytes 6, 7: (most symbols present in a block) - 1
+        *(u16*)(out + 6) = (u16)(ms ? ms - 1u : 0u);
+    }
     u32* w = (u32*)(out + 8);
     w[0] = g.kind | (g.pa ? 0x100u : 0u) | (g.ckw ? ANSX_KIND_WIDE_RESTART : 0u);  // bit 8: per-block alphabet compaction, bit 9: wide restart points
     w[1] = g.f;
@@ -2202,7 +2210,11 @@ __global__ __launch_bounds__(256) void k_assemble(ansx_geo g, const u32* __restr
             if (with_header) {
                 // ansx_container_header, little endian (include/ansx.h)
                 const char magic[8] = { 'A', 'N', 'S', 'X', 'v', '3', 0, 0 };
-                for (int i = 0; i < 8; i++) out[i] = (u8)magic[i];
+                for (int i = 0; i < 6; i++) out[i] = (u8)magic[i];
+                {
+                    const u32 ms = __hip_atomic_load(&gflags[ANSX_G_MAXSIGMA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(u16*)(out + 6) = (u16)(ms ? ms - 1u : 0u);  // bytes 6, 7: (most symbols present in a block) - 1
+                }
                 u32* w = (u32*)(out + 8);
                 w[0] = g.kind | (g.pa ? 0x100u : 0u) | (g.ckw ? ANSX_KIND_WIDE_RESTART : 0u);  // bit 8: per-block alphabet compaction, bit 9: wide restart points
                 w[1] = g.f;
@@ -3300,7 +3312,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
                 if (fr) {
                     const u64 base64 = ex & 0xFFFFFFFFull;
                     const u32 r = (u32)(ex >> 32);
-                    if (base64 < M && base64 + fr <= M) {  // (then r <= base < M and r <= s < max_ns)
+                    if (base64 < M && base64 + fr <= M && r < max_ns) {  // (max_ns here: the header's bound on symbols PRESENT in a block, i.e. the entries ep[] holds; untrusted like the rest)
                         const u32 base = (u32)base64;
                         // ANSrfold: the most-frequent values follow the 4-byte flag word
                         // (ans_reorder_fold.hpp:132-154)

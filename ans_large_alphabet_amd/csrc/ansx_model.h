@@ -644,5 +644,7 @@ __global__ __launch_bounds__(256, 6) void k_model_fused(const u32* __restrict__ 
             atomicMax(&gflags[ANSX_G_MAXLOGM], logM);
         if (__hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns)
             atomicMax(&gflags[ANSX_G_MAXNSYMS], ns);
+        if (__hip_atomic_load(&gflags[ANSX_G_MAXSIGMA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sigma)
+            atomicMax(&gflags[ANSX_G_MAXSIGMA], sigma);
     }
 }

@@ -16,7 +16,7 @@ import struct
 import torch
 
 HEADER_BYTES = 64
-MAGIC = b"ANSXv3\x00\x00"
+MAGIC = b"ANSXv3"  # followed by u16 (most symbols present in a block) - 1
 KIND_WIDE_RESTART = 0x200  # kind word bit 9: u32 cursors + 4 x u64 states instead of packed 29-byte restart points
 
 
@@ -53,16 +53,16 @@ def layout(nblocks, ckpts_per_block, wide=False):
 def parse_header(buf):
     """buf: 1-D uint8 tensor (any device).  Returns a dict of the 64-byte header."""
     raw = bytes(buf[:HEADER_BYTES].cpu().numpy().tobytes())
-    if raw[:8] != MAGIC:
+    if raw[:6] != MAGIC:
         raise ValueError("not an ansx container")
-    kind, f, n, block_ints, ckpt, nblocks, maxlg, maxns, nckf, payload_bytes, payload_off = struct.unpack(
-        "<IIQIIIIIIQQ", raw[8:])
-    return dict(kind=kind, f=f, n=n, block_ints=block_ints, ckpt=ckpt, nblocks=nblocks, max_log2_frame=maxlg,
+    mp, kind, f, n, block_ints, ckpt, nblocks, maxlg, maxns, nckf, payload_bytes, payload_off = struct.unpack(
+        "<HIIQIIIIIIQQ", raw[6:])
+    return dict(max_present_m1=mp, kind=kind, f=f, n=n, block_ints=block_ints, ckpt=ckpt, nblocks=nblocks, max_log2_frame=maxlg,
                 max_nsyms=maxns, ckpts_per_block=nckf, payload_bytes=payload_bytes, payload_offset=payload_off)
 
 
 def pack_header(h):
-    return MAGIC + struct.pack("<IIQIIIIIIQQ", h["kind"], h["f"], h["n"], h["block_ints"], h["ckpt"], h["nblocks"],
+    return MAGIC + struct.pack("<HIIQIIIIIIQQ", h["max_present_m1"], h["kind"], h["f"], h["n"], h["block_ints"], h["ckpt"], h["nblocks"],
                                h["max_log2_frame"], h["max_nsyms"], h["ckpts_per_block"], h["payload_bytes"],
                                h["payload_offset"])
 
@@ -128,7 +128,7 @@ def merge_containers(buf, sizes):
     merged = dict(h0)
     merged.update(n=sum(h["n"] for h in hs), nblocks=nblocks, payload_bytes=payload_bytes,
                   payload_offset=payload_off, max_log2_frame=max(h["max_log2_frame"] for h in hs),
-                  max_nsyms=max(h["max_nsyms"] for h in hs))
+                  max_nsyms=max(h["max_nsyms"] for h in hs), max_present_m1=max(h["max_present_m1"] for h in hs))
     out[:HEADER_BYTES] = torch.frombuffer(bytearray(pack_header(merged)), dtype=torch.uint8).to(dev)
     blk, pay = 0, 0
     index = []

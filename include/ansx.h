@@ -100,7 +100,10 @@ typedef struct {
 
 /* 64-byte container header (little endian), see DESIGN.md section 3. */
 typedef struct {
-    uint8_t magic[8];       /* "ANSXv3\0\0"                                                    */
+    uint8_t magic[6];       /* "ANSXv3"                                                         */
+    uint16_t max_present_m1; /* (max over blocks of the symbols PRESENT in the block) - 1: sizes the
+                               decoder's per-present-symbol table (<= max_nsyms - 1; untrusted
+                               like every other field: a block with more is a format error)     */
     uint32_t kind;          /* ansx_kind | 0x100 if ANSX_FLAG_COMPACT_ALPHABET | 0x200 if the restart
                                points are in the wide form (u32 cursor + 4 x u64 states: ANSint, frames
                                above 2^16, block streams of 16 MiB and more) instead of packed 29-byte

@@ -542,6 +542,8 @@ size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uin
     if (kind != ANS_ORACLE_RFOLD) {
         for (uint32_t i = 0; i < MAX_SIGMA; i++) local.sigma += (freqs[i] != 0);
     }
+    local.present_syms = 0;
+    for (uint32_t i = 0; i < MAX_SIGMA; i++) local.present_syms += (freqs[i] != 0);
     size_t nsyms = (size_t)max_sym + 1;
     uint32_t* nfreqs = (uint32_t*)calloc(nsyms, sizeof(uint32_t));
     uint64_t M = ans_oracle_adjust_freqs_ex(freqs, MAX_SIGMA, max_sym, nfreqs, kind != ANS_ORACLE_INT); /* :79; ans_int.hpp:50 */

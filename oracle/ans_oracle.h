@@ -33,6 +33,8 @@ typedef struct {
     uint32_t reorder_flag;  /* rfold: 0/1                                                  */
     uint64_t sigma;         /* rfold: number of distinct input values; fold: #nonzero syms */
     uint64_t final_states[4];
+    uint32_t present_syms;  /* symbols with a non-zero frequency in the block's model (every codec) */
+    uint32_t reserved;
 } ans_oracle_info;
 
 /* include/ans_fold.hpp:38-65 — folded symbol and number of exception bytes */

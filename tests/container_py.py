@@ -6,7 +6,7 @@ import numpy as np
 
 import oracle_lib as ol
 
-MAGIC = b"ANSXv3\x00\x00"
+MAGIC = b"ANSXv3"
 
 
 def nseg(nb, ckpt):
@@ -36,7 +36,7 @@ def build_container(kind, f, data, block, ckpt, wide=None):
         ckpt = 0
     nblocks = (n + block - 1) // block
     nckf = nseg(block, ckpt) - 1
-    streams, cks, cko, hints, maxlg, maxns = [], [], [], [], 0, 0
+    streams, cks, cko, hints, maxlg, maxns, maxsig = [], [], [], [], 0, 0, 0
     for b in range(nblocks):
         s, info, st, off = ol.oracle_encode(kind, f, data[b * block:(b + 1) * block], ckpt_interval=ckpt)
         streams.append(s)
@@ -49,6 +49,7 @@ def build_container(kind, f, data, block, ckpt, wide=None):
         cko.append(pad_o)
         maxlg = max(maxlg, info.log2_frame)
         maxns = max(maxns, info.max_sym + 1)
+        maxsig = max(maxsig, int(info.present_syms))  # symbols present in the block's model
     if wide is None:
         wide = (kind & 0xFF) == 3 or maxlg > 16
     index_off = 64
@@ -63,7 +64,7 @@ def build_container(kind, f, data, block, ckpt, wide=None):
     boff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     payload = np.concatenate(streams)
     out = np.zeros(payload_off + payload.size, dtype=np.uint8)
-    hdr = MAGIC + struct.pack("<IIQIIIIIIQQ", kind | (0x200 if wide else 0), f, n, block, ckpt, nblocks, maxlg, maxns, nckf,
+    hdr = MAGIC + struct.pack("<HIIQIIIIIIQQ", max(maxsig, 1) - 1, kind | (0x200 if wide else 0), f, n, block, ckpt, nblocks, maxlg, maxns, nckf,
                               int(payload.size), payload_off)
     out[:64] = np.frombuffer(hdr, dtype=np.uint8)
     out[index_off:index_off + 8 * (nblocks + 1)] = boff.view(np.uint8)

@@ -27,6 +27,8 @@ class OracleInfo(C.Structure):
         ("reorder_flag", C.c_uint32),
         ("sigma", C.c_uint64),
         ("final_states", C.c_uint64 * 4),
+        ("present_syms", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

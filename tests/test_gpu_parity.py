@@ -533,6 +533,34 @@ def test_restart_point_formats(A):
     c3.close()
 
 
+def test_header_bound_on_present_symbols_is_untrusted(A):
+    """Header bytes 6, 7 = (most symbols present in a block) - 1 size the decoder's per-present-symbol table in LDS.
+    It equals the oracle's count; a container that claims fewer than its blocks hold is a format error -- on a fresh
+    context and on one that remembers the honest header of the same shape -- never a write past the table."""
+    n, block = 50001, 8192
+    data = ol.gen_inputs("zipf24", n, seed=9)
+    for kind, f in ((ol.FOLD, 3), (ol.RFOLD, 1), (ol.FOLD, 5)):
+        d = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7)))) if kind == ol.RFOLD else data
+        c0 = A.Context(0)
+        codec = codec_for(A, c0, kind, f, block_ints=block, ckpt_interval=1024)
+        cont = codec.encode(d)
+        H = A.parse_container(cont)["header"]
+        present = max(int(ol.oracle_encode(kind, f, d[b * block:(b + 1) * block])[1].present_syms) for b in range(H.nblocks))
+        assert H.max_present_m1 + 1 == present <= H.max_nsyms
+        assert np.array_equal(codec.decode(cont, n), d)  # (the context now remembers this header)
+        for claim in (0, present // 2, present - 2):
+            bad = cont.copy()
+            bad[6], bad[7] = claim & 0xFF, claim >> 8
+            for ctxx in (c0, A.Context(0)):
+                with pytest.raises(A.AnsxError) as e:
+                    codec_for(A, ctxx, kind, f, block_ints=block, ckpt_interval=1024).decode(bad, n)
+                assert e.value.status == 3  # ANSX_ERR_FORMAT
+                if ctxx is not c0:
+                    ctxx.close()
+        assert np.array_equal(codec.decode(cont, n), d)
+        c0.close()
+
+
 def test_rank_shards_merge_into_one_decodable_container(A, ctx):
     """Multi-GPU data path on one device: encode two contiguous block ranges separately (what
     two ranks do), merge on the 'root' (index rebase), decode the merged container as a whole."""

@@ -829,8 +829,10 @@ __global__ __launch_bounds__(64) void k_select_model(ansx_geo g, u32 NSP, u32 ba
     }
     // (ANSint frames may exceed 2^16 -- 32-bit frequencies, ans_int.hpp:30-34,50: the 16-byte table entries, the
     // integer-state encoder and the slot -> symbol decoder take any frame the reference's own arithmetic survives;
-    // beyond 2^27 its 64-bit renormalisation bound K * RADIX * freq overflows, so that is where this build stops)
-    if (chosen >= 0 && g.kind == 3 && B->m0_log2 + (u32)chosen > 27) chosen = -1;
+    // beyond 2^27 its 64-bit renormalisation bound K * RADIX * freq overflows, so that is where this build stops.
+    // The 16-bit codecs stop there too: their state update (quotient below 2^36) << log2 M leaves 64 bits at 2^28 --
+    // in the reference as well -- and the prelude writer's 32-bit code arithmetic relies on frames below 2^30.)
+    if (chosen >= 0 && B->m0_log2 + (u32)chosen > 27) chosen = -1;
     if (chosen < 0) {  // "prev" is the all-zero vector: reference's degenerate exit
         if (lane == 0) {
             B->resolved = 1;
@@ -1259,7 +1261,7 @@ __global__ __launch_bounds__(256) void k_write_prelude(ansx_geo g, u32 NSP,
         __threadfence_block();
     }
     __syncthreads();
-    prelude_emit<IPT>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);
+    prelude_emit<IPT, false, true>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (universe 2^logM + ns + 1 < 2^31: frames end at 2^27)
 }
 
 // ------------------------------------------------------------------------------------------

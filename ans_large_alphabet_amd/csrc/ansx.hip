@@ -486,7 +486,11 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // Fast model path (ansx_fastmodel.h): geometries seen before, whole-block histograms, 16-bit frequencies,
     // compact tables; every assumption is checked on the device and a miss repeats the call on the exact path.
     const u32 NT = optimistic ? c->cur_nt : 0u;
-    const bool fast = NT != 0 && !g.pa && h_deferred && g.block_ints <= 65535u && NSP <= 4096 && !c->dbg.table16_fixup
+    // (alphabets above 4096 slots -- f = 4, 5 -- take the generic form of k_model_finish as long as its three LDS arrays,
+    // sized from the alphabet hint, fit a CU; ANSint has no u16 rule and 32-bit frequencies: exact path)
+    const u32 fcap_probe = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
+    const bool fast = NT != 0 && !g.pa && h_deferred && g.block_ints <= 65535u && NSP <= 16384 && g.kind != ANSX_INT
+        && (NSP <= 4096 || (size_t)fcap_probe * 12 + 64 <= 150 * 1024) && !c->dbg.table16_fixup
         && !c->dbg.encode_gtab16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
     c->used_fast = fast;
     if (fast) {
@@ -507,8 +511,9 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         const size_t packed_lds = (size_t)NSP * 2;
         if (packed_lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_fold_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)packed_lds));
+        // (sum_mode bit 1: on the fast model path H is the workgroup's tree sum and there is no hterm array to write)
         LAUNCH(c, "k_fold_hist", k_fold_hist<true>, (size_t)NB * cpb, 256, packed_lds, s, src, g, chunk, cpb, NSP, hist, hterm,
-            0u, blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
+            fast ? 2u : 0u, blk, gflags, (g.kind == ANSX_INT && !g.pa) ? NSP : (1u << 30));
     } else {
         if (hist_lds > 48 * 1024)
             HIPCHK(c, hipFuncSetAttribute((const void*)k_fold_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
@@ -588,6 +593,9 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     } while (0)
         if (NSP <= 1024) {
             ANSX_LAUNCH_FIN(4, 8);  // (wave-per-candidate form: NTC is not used)
+        } else if (NSP > 4096) {
+            if (NT <= 5) ANSX_LAUNCH_FIN(0, 5);
+            else ANSX_LAUNCH_FIN(0, 8);
         } else {
             if (NT <= 5) ANSX_LAUNCH_FIN(16, 5);
             else ANSX_LAUNCH_FIN(16, 8);
@@ -1032,7 +1040,7 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
     int rc = ANSX_RETRY_GENERAL;
     const auto it = c->ns_hint.find(key);
     const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
-    const bool eligible = !P.plain && hint != 0 && P.NSP <= 4096 && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
+    const bool eligible = !P.plain && hint != 0 && (P.NSP <= 4096 || (P.NSP <= 16384 && P.g.kind != ANSX_INT && !P.g.pa)) && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
         && !c->dbg.model_sync;  // (with compaction too: the hint then describes the alphabets of the rank-remapped blocks)
     const auto rit = c->rf_hint.find(key);
     c->cur_rf_slots = (eligible && P.g.kind == ANSX_RFOLD && rit != c->rf_hint.end()) ? rf_opt_slots(rit->second, fold_T(P.g.f)) : 0u;

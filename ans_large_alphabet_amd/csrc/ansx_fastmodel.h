@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     // Alphabets up to 1024 slots (IPT == 4) keep the round-3 form -- wave w takes the candidates w and w + 4, lane l
     // the chunks l, l + 64 -- because the all-candidates form needs 96 registers instead of 66 (5 instead of 7 waves per
     // SIMD) and measured slower there (0.175 vs 0.155 ms); on 4096-slot alphabets it is the faster one (0.38 -> 0.34).
-    constexpr bool ALLT = IPT > 4;
+    constexpr bool ALLT = IPT > 4 || IPT == 0;  // (IPT == 0: any alphabet the LDS holds -- loops instead of register arrays)
     u32 fs0[8] = {};
     uint4 sv0[NTC] = {};
     if constexpr (ALLT) {
@@ -481,30 +481,57 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     STAMP(5);
     __syncthreads();
     STAMP(6);
-    const u32 s0 = tid * IPT;
-    u32 fr[IPT];
-    u32 sum = 0;
-#pragma unroll
-    for (int i = 0; i < IPT; i += 4) {
-        uint4 f4 = make_uint4(0u, 0u, 0u, 0u);
-        if (s0 + i < cap) f4 = *(const uint4*)(frq + s0 + i);  // cap is a multiple of 16
-        fr[i] = f4.x, fr[i + 1] = f4.y, fr[i + 2] = f4.z, fr[i + 3] = f4.w;
-        sum += f4.x + f4.y + f4.z + f4.w;
-    }
     u32 total;
-    u32 base = block_excl_scan<u32>(sum, sh_part, tid, 256, &total);
-    STAMP(7);
-    if (s0 < ns) {
-        u32* t32 = tab32 + (u64)b * NSP + s0;
+    if constexpr (IPT > 0) {
+        const u32 s0 = tid * IPT;
+        u32 fr[IPT > 0 ? IPT : 4];
+        u32 sum = 0;
 #pragma unroll
         for (int i = 0; i < IPT; i += 4) {
+            uint4 f4 = make_uint4(0u, 0u, 0u, 0u);
+            if (s0 + i < cap) f4 = *(const uint4*)(frq + s0 + i);  // cap is a multiple of 16
+            fr[i] = f4.x, fr[i + 1] = f4.y, fr[i + 2] = f4.z, fr[i + 3] = f4.w;
+            sum += f4.x + f4.y + f4.z + f4.w;
+        }
+        u32 base = block_excl_scan<u32>(sum, sh_part, tid, 256, &total);
+        STAMP(7);
+        if (s0 < ns) {
+            u32* t32 = tab32 + (u64)b * NSP + s0;
+#pragma unroll
+            for (int i = 0; i < IPT; i += 4) {
+                u32 w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 s = s0 + i + k;
+                    w4[k] = (base << 16) | fr[i + k];  // valid while M <= 65536 (base < 2^16, freq < 65535)
+                    if (s < ns) inc[s] = base + fr[i + k] + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
+                    base += fr[i + k];
+                }
+                *(uint4*)(t32 + i) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
+    } else {
+        // any alphabet: thread i owns `per` consecutive symbols (a multiple of 4) and walks them twice
+        const u32 per = ((cap + 255u) / 256u + 3u) & ~3u;
+        const u32 s0 = tid * per;
+        u32 sum = 0;
+        for (u32 i = 0; i < per && s0 + i < cap; i += 4) {
+            const uint4 f4 = *(const uint4*)(frq + s0 + i);  // cap is a multiple of 16
+            sum += f4.x + f4.y + f4.z + f4.w;
+        }
+        u32 base = block_excl_scan<u32>(sum, sh_part, tid, 256, &total);
+        STAMP(7);
+        u32* t32 = tab32 + (u64)b * NSP + s0;
+        for (u32 i = 0; i < per && s0 + i < cap && s0 + i < ((ns + 3u) & ~3u); i += 4) {
+            const uint4 f4 = *(const uint4*)(frq + s0 + i);
+            const u32 f[4] = { f4.x, f4.y, f4.z, f4.w };
             u32 w4[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const u32 s = s0 + i + k;
-                w4[k] = (base << 16) | fr[i + k];  // valid while M <= 65536 (base < 2^16, freq < 65535)
-                if (s < ns) inc[s] = base + fr[i + k] + s;  // ans_util.hpp:54-58: inc[s] = inc[s-1] + nfreq[s] + 1
-                base += fr[i + k];
+                w4[k] = (base << 16) | f[k];
+                if (s < ns) inc[s] = base + f[k] + s;
+                base += f[k];
             }
             *(uint4*)(t32 + i) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }

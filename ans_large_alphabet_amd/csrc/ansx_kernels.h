@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_fold_hist(const u32* __restrict__ in, a
             const double t = term(fr);
             if (tree_sum) part = part + t;
             else if (sum_here) lds_term[s] = t;
-            else ht[s] = t;
+            else if (ht != nullptr) ht[s] = t;  // (no array: a launch-site error must not become a write to address 0)
         }
         if (tree_sum) {
             part = wave_sum(part);

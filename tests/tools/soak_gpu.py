@@ -13,6 +13,9 @@ kernel changes, hint-sized ANSrfold hash tables with their overflow-and-repeat p
 Round 3 (fast model path, container v3, DPP scans; plain ANSint and the restart points of every checked block added to the
 cases): 90 885 iterations (seed 41, 400 s) and, with the final kernels, 54 106 (seed 51, 240 s), 0 failures, 0 near-threshold decisions;
 SOAK_F67=1 (fidelities 5..7 only: the HBM-backed large-alphabet stages): 33 637 iterations (seed 61, 300 s), 0 failures.
+End of round 3 (decoder table sized by the header's present-symbol bound, fast model path for f = 4, 5 -- whose first build
+this tool caught writing through a null array before it was committed): 81 402 iterations (seed 71, 360 s) and 27 445 with
+SOAK_F67=1 (seed 81, 240 s), 0 failures.
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

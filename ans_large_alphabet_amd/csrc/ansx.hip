@@ -490,7 +490,7 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // sized from the alphabet hint, fit a CU; ANSint has no u16 rule and 32-bit frequencies: exact path)
     const u32 fcap_probe = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
     const bool fast = NT != 0 && !g.pa && h_deferred && g.block_ints <= 65535u && NSP <= 16384 && g.kind != ANSX_INT
-        && (NSP <= 4096 || (size_t)fcap_probe * 12 + 64 <= 150 * 1024) && !c->dbg.table16_fixup
+        && (NSP <= 4096 || (size_t)fcap_probe * 8 + 64 <= 150 * 1024) && !c->dbg.table16_fixup
         && !c->dbg.encode_gtab16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
     c->used_fast = fast;
     if (fast) {
@@ -583,13 +583,15 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
 #undef ANSX_LAUNCH_CAND
 #undef ANSX_LAUNCH_CAND2
         const u32 fcap = std::min<u32>(NSP, std::max<u32>(64u, (ns_cap + 15u) & ~15u));
-        const size_t fl = (size_t)fcap * 12 + 64;
+        const bool fin_generic = NSP > 4096;  // (loop-based form: inc[] in the block's histogram row, two LDS arrays)
+        const size_t fl = (size_t)fcap * (fin_generic ? 8 : 12) + 64;
 #define ANSX_LAUNCH_FIN(IPT_, NTC_)                                                                                    \
     do {                                                                                                            \
         if (fl > 48 * 1024)                                                                                         \
             HIPCHK(c, hipFuncSetAttribute((const void*)k_model_finish<IPT_, NTC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
         LAUNCH(c, "k_model_finish", (k_model_finish<IPT_, NTC_>), NB, 256, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p, \
-            (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo); \
+            (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo, \
+            fin_generic ? hist : (u32*)nullptr); \
     } while (0)
         if (NSP <= 1024) {
             ANSX_LAUNCH_FIN(4, 8);  // (wave-per-candidate form: NTC is not used)

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     const uint4* __restrict__ srank, const u32* __restrict__ attMeta, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
     u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard, const double* __restrict__ lg2i,
-    const uint2* __restrict__ geo)
+    const uint2* __restrict__ geo, u32* __restrict__ incbuf = nullptr)
 {
     static_assert(IPT % 4 == 0, "table rows are written 16 bytes at a time");
     static_assert(ANSX_FIN_LUT == 512, "two table entries per thread");
@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     ansx_blk* B = &blk[b];
     u32* off = lds32;             // [cap]
     u32* bits = lds32 + cap;      // bit buffer; until the prelude is written: the chosen frequencies by symbol
-    u32* inc = lds32 + 2 * cap;   // [cap]
+    // incbuf (IPT == 0): inc[] in HBM (the block's histogram row, free by now) instead of a third LDS array -- 8 instead
+    // of 12 bytes of LDS per symbol, i.e. two workgroups per CU on 8000-symbol alphabets
+    const bool inc_hbm = IPT == 0 && incbuf != nullptr;
+    u32* inc = inc_hbm ? incbuf + (u64)b * NSP : lds32 + 2 * cap;   // [cap]
+    const u32 dump = inc_hbm ? cap + 8u : 2u * cap + 8u;  // scratch word (relative to frq) behind the LDS arrays
     u32* frq = bits;
     STAMP(0);
     // ---- requests: everything the cross entropy of ALL candidates needs of 8-rank chunk `tid` -- its (F | sym << 16)
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         const u32 sv8[8] = { sq.x & 0xFFFFu, sq.x >> 16, sq.y & 0xFFFFu, sq.y >> 16, sq.z & 0xFFFFu, sq.z >> 16, sq.w & 0xFFFFu, sq.w >> 16 };
         // (symbols of a block are below ns <= cap; ranks past sigma go to a scratch word behind the three arrays)
 #pragma unroll
-        for (int i = 0; i < 8; i++) frq[c * 8u + i < sigma ? fs[i] >> 16 : 2u * cap + 8u] = sv8[i];
+        for (int i = 0; i < 8; i++) frq[c * 8u + i < sigma ? fs[i] >> 16 : dump] = sv8[i];
     };
     if constexpr (ALLT) {
         double w[NTC];
@@ -551,6 +555,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             atomicMax(&gflags[ANSX_G_MAXT], (u32)chosen);
     }
     STAMP(8);
+    if (inc_hbm) __threadfence_block();  // (inc[] went to HBM: visible to the workgroup behind the barrier)
     __syncthreads();  // frq (= bits) has been read by everyone; inc[] is complete
     STAMP(9);
 #ifndef FIN_NO_PRELUDE

@@ -15,7 +15,7 @@ cases): 90 885 iterations (seed 41, 400 s) and, with the final kernels, 54 106 (
 SOAK_F67=1 (fidelities 5..7 only: the HBM-backed large-alphabet stages): 33 637 iterations (seed 61, 300 s), 0 failures.
 End of round 3 (decoder table sized by the header's present-symbol bound, fast model path for f = 4, 5 -- whose first build
 this tool caught writing through a null array before it was committed): 81 402 iterations (seed 71, 360 s) and 27 445 with
-SOAK_F67=1 (seed 81, 240 s), 0 failures.
+SOAK_F67=1 (seed 81, 240 s; again 22 934 with seed 91 after k_model_finish<0> moved inc[] to HBM), 0 failures.
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

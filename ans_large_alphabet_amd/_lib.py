@@ -26,7 +26,7 @@ EXPORTS = [
     "ansx_container_info", "ansx_profile_enable", "ansx_profile_reset", "ansx_profile_get",
     "ansx_workspace_bytes", "ansx_host_log2", "ansx_selftest_log2", "ansx_selftest_div", "ansx_debug_set",
     "ansx_generate_dev", "ansx_generate_host", "ansx_last_encode_stats", "ansx_merge_containers_dev",
-    "ansx_zipf_from_uniform", "ansx_gather_containers",
+    "ansx_zipf_from_uniform", "ansx_gather_containers", "ansx_last_gather_ranks",
 ]
 
 
@@ -132,6 +132,8 @@ def lib():
     L.ansx_merge_containers_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int, vp, sz, C.POINTER(sz), vp]
     L.ansx_last_encode_stats.restype = C.c_int
     L.ansx_last_encode_stats.argtypes = [vp, C.POINTER(EncodeStats)]
+    L.ansx_last_gather_ranks.restype = C.c_int
+    L.ansx_last_gather_ranks.argtypes = [vp]
     L.ansx_debug_set.restype = C.c_int
     L.ansx_debug_set.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.ansx_zipf_from_uniform.restype = C.c_int

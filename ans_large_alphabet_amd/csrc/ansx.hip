@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -63,7 +64,9 @@ struct ansx_ctx {
     // header of the last container decoded per (kind, fidelity, n, bytes): the next decode of that shape is launched
     // on it without waiting for the header to come back, and a one-thread kernel compares it with the real one
     std::map<std::array<u64, 4>, ansx_container_header> hdr_cache;
+    std::deque<std::array<u64, 4>> hdr_order;  // keys of hdr_cache, oldest first (an erased key may linger: erase is idempotent)
     std::map<u32, DevBuf> geo;   // tree nodes of the interpolative code per alphabet size, tabulated per symbol-array size (<= 4096)
+    int last_gather_ranks = 0;   // ranks of the communicator the last ansx_gather_containers call ran on (ncclCommCount)
     std::set<u64> wide_hint;     // geometries that met a frame above 2^16: wide restart points from the start
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
     const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
@@ -245,6 +248,8 @@ int make_plan(int kind, int f, size_t n, const ansx_opts* opts, Plan* P)
     g.pa = pa ? 1u : 0u;
     g.ckw = 0;            // packed restart points unless set_restart_format() says otherwise
     g.payload_bytes = 0;  // (set by decode_dev from the container header)
+    g.trusted_index = 0;  // (set by decode_dev on the single-stream path only, where the host writes the two entries)
+    g.pad_ = 0;
     g.map = kind == ANSX_MSB ? map_msb() : (kind == ANSX_INT ? map_int() : map_fold((u32)f));
     P->g = g;
     // symbol-array stride: the reference's MAX_SIGMA (ans_fold.hpp:70; ans_msb.hpp:28 has 1280)
@@ -880,7 +885,7 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
             d_out + P.lay.payload_off, gflags);
         LAUNCH(c, "k_write_header", k_write_header, 1, 64, 0, s, g, d_out, gflags, result, P.lay.payload_off);
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const u32 fl = c->h_pin[ANSX_G_ERR];
     if (fl & (1u << 6)) return ANSX_ERR_DOMAIN;
@@ -1111,8 +1116,21 @@ int encode_dev(ansx_ctx* c, const Plan& P0, const u32* d_in, u8* d_out, size_t c
         const u64 key = ((u64)P.g.pa << 48) | ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
         const size_t stream_bound = block_bound(P.g.kind, P.g.f, P.g.block_ints, P.g.pa != 0) + 16;
         const bool must = P.g.kind == ANSX_INT || stream_bound >= ((size_t)1 << ANSX_CK_CURSOR_BITS) || c->dbg.wide_restart;
-        set_restart_format(&P, must || c->wide_hint.count(key) != 0);
+        // The hint only picks which attempt runs FIRST; the format that is returned is a function of the input and the
+        // options alone: wide if and only if this call's frames need it.
+        const bool hinted = !must && c->wide_hint.count(key) != 0;
+        set_restart_format(&P, must || hinted);
         int rc = encode_dev_once(c, P, d_in, d_out, cap, out_bytes, s);
+        if (rc == ANSX_OK && hinted && c->last.max_log2_frame <= c->dbg.wide_at) {
+            // an earlier call of this geometry needed wide restart points, this input does not: encode it again packed, so
+            // that equal inputs give equal containers whatever the context encoded before (ranks of a multi-GPU job must
+            // agree on the format, ansx_merge_containers_dev), and forget the hint
+            c->wide_hint.erase(key);
+            set_restart_format(&P, false);
+            const u32 path0 = c->last.path;
+            rc = encode_dev_once(c, P, d_in, d_out, cap, out_bytes, s);
+            c->last.path |= (path0 & 16u) | 64u;  // 64: repeated with packed restart points
+        }
         if (rc != ANSX_RETRY_WIDE) return rc;
         c->wide_hint.insert(key);
         set_restart_format(&P, true);
@@ -1382,6 +1400,7 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         // this call's final read-back, which the stream orders behind this copy)
         u64* hb = (u64*)((u8*)c->h_pin + 64 + 32);
         hb[0] = 0, hb[1] = (u64)in_bytes;
+        P.g.trusted_index = 1;  // the index of this one block is the pair written here, not container bytes
         u64* boff_ws = (u64*)((u8*)c->misc.p + 64);
         HIPCHK(c, hipMemcpyAsync(boff_ws, hb, 16, hipMemcpyHostToDevice, s));
         cont = (const u8*)c->plain.p;
@@ -1423,6 +1442,9 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
         // (written so that a crafted payload_bytes near 2^64 cannot wrap the sum; payload_offset covers
         // the index and the restart-point area, so this also places those inside the input)
         if (H.payload_offset > in_bytes || H.payload_bytes > in_bytes - H.payload_offset) return ANSX_ERR_FORMAT;
+        // every block stream has a minimum length (index_entry_ok): a payload shorter than that for all blocks is malformed
+        // whatever the index says (in particular payload_bytes == 0, which no parser may take for "no index")
+        if (H.payload_bytes < (u64)P.g.nblocks * (P.g.pa ? 8u : 38u)) return ANSX_ERR_FORMAT;
         // (with compaction a list whose blocks all hold a single distinct value has no model at all)
         if (H.max_log2_frame > 31 || (H.max_nsyms == 0 && !P.g.pa) || H.max_nsyms > P.NSP) return ANSX_ERR_FORMAT;
         maxM = 1u << H.max_log2_frame;
@@ -1486,8 +1508,16 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
     if (!P.plain && !spec && st == ANSX_OK) {
         ansx_container_header Hc;
         memcpy(&Hc, (u8*)c->h_pin + 64, sizeof(Hc));
+        if (c->hdr_cache.find(hkey) == c->hdr_cache.end()) {
+            // evict the OLDEST remembered shape (insertion order), never the one being stored
+            c->hdr_order.erase(std::remove(c->hdr_order.begin(), c->hdr_order.end(), hkey), c->hdr_order.end());  // (left behind by a mismatch)
+            c->hdr_order.push_back(hkey);
+            while (c->hdr_order.size() > 64) {
+                c->hdr_cache.erase(c->hdr_order.front());
+                c->hdr_order.pop_front();
+            }
+        }
         c->hdr_cache[hkey] = Hc;
-        if (c->hdr_cache.size() > 64) c->hdr_cache.erase(c->hdr_cache.begin());
     }
     return st;
 }
@@ -1501,6 +1531,7 @@ struct RcclApi {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;  // optional: only reported (ansx_last_gather_ranks)
     bool ok = false;
 };
 const RcclApi& rccl_api()
@@ -1515,6 +1546,7 @@ const RcclApi& rccl_api()
         a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
         a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
         a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+        a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
         a.ok = a.AllGather && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
         return a;
     }();
@@ -1626,6 +1658,14 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
     else if (!strcmp(name, "ANSX_WIDE_RESTART")) c->dbg.wide_restart = on;
+    else if (!strcmp(name, "ANSX_FORGET_HINTS")) {  // the next call of every geometry is a first call again (bench.py: first_call_ms)
+        c->ns_hint.clear();
+        c->rf_hint.clear();
+        c->t_hint.clear();
+        c->wide_hint.clear();
+        c->hdr_cache.clear();
+        c->hdr_order.clear();
+    }
     else if (!strcmp(name, "ANSX_TEST_WIDE_AT")) {
         const u32 v = (value && value[0]) ? (u32)strtoul(value, nullptr, 10) : 16u;
         if (v > 16) return ANSX_ERR_ARG;
@@ -1894,20 +1934,25 @@ int ansx_gather_containers(ansx_ctx* c, void* nccl_comm, int rank, int nranks, i
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     ncclComm_t comm = (ncclComm_t)nccl_comm;
     *merged_bytes = 0;
-    // 1. sizes of all rank containers, everywhere (a rank that does not fit its slot fails the call on every rank)
+    // 1. sizes of all rank containers AND every rank's idea of slot_bytes, everywhere: the capacity check below uses the
+    //    ROOT's slot_bytes on every rank, so that all ranks take the same branch (a rank that returned early on its own
+    //    value would leave the root waiting in its ncclRecv)
     int rc;
-    if ((rc = ensure(c, c->misc, 64 + 8 * ((size_t)ANSX_MERGE_MAX_PARTS + 2)))) return rc;
+    if ((rc = ensure(c, c->misc, 64 + 8 * (3 * (size_t)ANSX_MERGE_MAX_PARTS + 2)))) return rc;
     u64* d_sizes = (u64*)((u8*)c->misc.p + 64);
     u64* h_sizes = (u64*)((u8*)c->h_pin + 64);
-    const u64 mine = (u64)bytes;
-    HIPCHK(c, hipMemcpyAsync(d_sizes + ANSX_MERGE_MAX_PARTS, &mine, 8, hipMemcpyHostToDevice, s));
-    if (R.AllGather(d_sizes + ANSX_MERGE_MAX_PARTS, d_sizes, 1, ncclUint64, comm, s) != ncclSuccess) return ANSX_ERR_HIP;
-    HIPCHK(c, hipMemcpyAsync(h_sizes, d_sizes, 8 * (size_t)nranks, hipMemcpyDeviceToHost, s));
+    const u64 mine[2] = { (u64)bytes, (u64)slot_bytes };
+    HIPCHK(c, hipMemcpyAsync(d_sizes + 2 * ANSX_MERGE_MAX_PARTS, mine, 16, hipMemcpyHostToDevice, s));
+    if (R.AllGather(d_sizes + 2 * ANSX_MERGE_MAX_PARTS, d_sizes, 2, ncclUint64, comm, s) != ncclSuccess) return ANSX_ERR_HIP;
+    HIPCHK(c, hipMemcpyAsync(h_sizes, d_sizes, 16 * (size_t)nranks, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    int comm_ranks = 0;
+    if (R.CommCount && R.CommCount(comm, &comm_ranks) == ncclSuccess) c->last_gather_ranks = comm_ranks;
+    const u64 root_slot = h_sizes[2 * root + 1];
     std::vector<size_t> sizes((size_t)nranks);
     for (int r = 0; r < nranks; r++) {
-        sizes[(size_t)r] = (size_t)h_sizes[r];
-        if (h_sizes[r] > slot_bytes || h_sizes[r] < sizeof(ansx_container_header)) return ANSX_ERR_CAPACITY;
+        sizes[(size_t)r] = (size_t)h_sizes[2 * r];
+        if (h_sizes[2 * r] > root_slot || h_sizes[2 * r] < sizeof(ansx_container_header)) return ANSX_ERR_CAPACITY;
     }
     // 2. every rank's container into its slot on the root
     if (R.GroupStart() != ncclSuccess) return ANSX_ERR_HIP;
@@ -1926,6 +1971,8 @@ int ansx_gather_containers(ansx_ctx* c, void* nccl_comm, int rank, int nranks, i
     for (int r = 0; r < nranks; r++) parts[(size_t)r] = d_recv + (size_t)r * slot_bytes;
     return ansx_merge_containers_dev(c, parts.data(), sizes.data(), nranks, d_merged, merged_cap, merged_bytes, s);
 }
+
+int ansx_last_gather_ranks(const ansx_ctx* c) { return c ? c->last_gather_ranks : 0; }
 
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out)
 {

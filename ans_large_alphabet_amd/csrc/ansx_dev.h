@@ -313,6 +313,10 @@ struct ansx_geo {
     u32 ckw;         // restart points: 0 = packed 29-byte records, 1 = wide (u32 cursor + 4 x u64 states), see below
     ansx_map map;    // value <-> symbol map of this codec
     u64 payload_bytes;  // decode: bytes of block streams behind the container's payload offset (0 on the encode side)
+    u32 trusted_index;  // decode: 1 = the two index entries were written by the host itself (single-stream mode: the
+                        // plain reference stream has no index); 0 = they come from the container and every parser checks
+                        // the pair of its own block (index_entry_ok).  Never derived from a container field.
+    u32 pad_;
 };
 
 // Restart points in the container index.  A state is below 2^36 M and a cursor below the block's

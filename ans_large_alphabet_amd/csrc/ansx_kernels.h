@@ -2297,7 +2297,7 @@ __device__ __forceinline__ parse_hdr parse_header(const u8* __restrict__ cont, c
     const u32 T = fold_T(g.f);
     u32 err = 0, ns = 0, logM = 0, flag = 0;
     const u64 boff = block_off[b], boff1 = block_off[b + 1];
-    if (g.payload_bytes != 0 && !index_entry_ok(g, b, boff, boff1)) {  // (single-stream mode has no index: payload_bytes 0)
+    if (!g.trusted_index && !index_entry_ok(g, b, boff, boff1)) {  // (single-stream mode: the host wrote the two entries itself)
         parse_hdr Hb;
         Hb.err = 1, Hb.ns = 1, Hb.logM = 0, Hb.flag = 0, Hb.pos = 0, Hb.sbytes = 0, Hb.stream = cont;
         return Hb;

@@ -302,6 +302,42 @@ def pmc_traffic(kernel, workload):
         return None, "unreadable PMC summary: %r" % (exc,)
 
 
+# SIMD-level issue cost of a vector instruction on gfx950 (tests/tools/ubench_valu2.hip, round 4: four waves per SIMD of
+# independent f64 / VOP3 / DPP instructions retire one per 4.1-4.7 cycles and SIMD; only 4-byte-encoded 32-bit VOP1/VOP2
+# forms reach 2.4) and the clock the chip holds in these loops
+ISSUE_CYCLES_PER_VALU = 4.3
+ISSUE_CLOCK_GHZ = 2.1
+N_SIMD = 1024
+
+
+def issue_floor(kernel, workload_hint=None):
+    """Lower bound on `kernel`'s duration from instruction issue alone: the vector instructions ALL its waves execute
+    (SQ_INSTS_VALU from the newest committed rocprofv3 SQ-counter summary, profiles/*_sq_counters.json) spread evenly over
+    the chip's 1024 SIMDs at ISSUE_CYCLES_PER_VALU cycles each.  Says which bound a kernel is against next to the HBM
+    fraction: a kernel at 0.25 of the HBM peak whose issue floor is 60 % of its duration is not going to be fixed by
+    memory-side work.  Returns (ms, source) or (None, reason)."""
+    try:
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+        for path in reversed(paths):
+            with open(path) as fh:
+                doc = json.load(fh)
+            if workload_hint and doc.get("workload") not in (None, workload_hint):
+                continue
+            for name, v in doc.get("kernels", {}).items():
+                base = name.split("<")[0]
+                if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode"):
+                    # (collect.sh profiles `bench.py --steps 1 --warmup 0`: the discovery step + the timed one = 2 launches of
+                    # every per-step kernel; summaries written since round 4 carry the dispatch count themselves)
+                    waves = float(v["waves"]) / max(1.0, float(v.get("launches", 2)))
+                    insts = float(v["SQ_INSTS_VALU_per_wave"]) * waves
+                    ms = insts * ISSUE_CYCLES_PER_VALU / N_SIMD / (ISSUE_CLOCK_GHZ * 1e9) * 1e3
+                    return ms, ("%s: %.0f VALU instructions per wave x %.0f waves per launch, %.1f cycles each per SIMD at %.1f GHz"
+                                % (os.path.relpath(path, ROOT), v["SQ_INSTS_VALU_per_wave"], waves, ISSUE_CYCLES_PER_VALU, ISSUE_CLOCK_GHZ))
+        return None, "no SQ-counter summary for this kernel under profiles/"
+    except Exception as exc:  # noqa: BLE001
+        return None, "unreadable SQ summary: %r" % (exc,)
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -335,10 +371,59 @@ def kernel_profile(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream, c_byt
            "k_rfold_remap": 8.0 * n}.get(dom, 4.0 * n)
     achieved = alg / (avg_ms * 1e-3) / 1e9
     traffic, source = pmc_traffic(dom, workload)
+    floor_ms, floor_src = issue_floor(dom, workload)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
-                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms}
+                "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms,
+                "issue_floor_ms": floor_ms, "issue_floor_source": floor_src}
     return kernels, roofline
+
+
+def single_stream_row(torch, A, ctx, device, codec_name, fidelity, d_in, m=4 * (1 << 20)):
+    """ANSX_SINGLE_STREAM: ONE plain reference stream for the whole list (the bytes of ANSfold<f>::encode, decodable by the
+    reference) -- four lanes of one wave, there for byte compatibility, not speed.  Timed on the first m ints."""
+    codec = make_codec(A, ctx, codec_name, fidelity, block=A.SINGLE_STREAM)
+    m = min(m, d_in.numel())
+    cap = codec.bound(m)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+    d_back = torch.zeros(m, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    best = [1e30, 1e30]
+    nb = 0
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = codec.encode_dev(d_in.data_ptr(), m, d_out.data_ptr(), cap, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), m, stream=stream)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best = [min(best[0], t1 - t0), min(best[1], t2 - t1)]
+    ok = bool(torch.equal(d_back, d_in[:m]))
+    return {"ints": m, "enc_mints": m / best[0] / 1e6, "dec_mints": m / best[1] / 1e6, "value": m / (best[0] + best[1]) / 1e6,
+            "unit": "Mints/s", "bits_per_int": 8.0 * nb / m, "roundtrip_ok": ok}
+
+
+def first_call_row(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream):
+    """The first encode + decode of a geometry on a context that knows nothing about it: the encoder reads the largest
+    alphabet back mid-call and runs the exact model kernels, the decoder reads the header back before it launches anything
+    (stats.path 0).  The steady state the headline quotes starts with the second call."""
+    ctx.debug_set("ANSX_FORGET_HINTS", "1")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+    path = ctx.last_encode_stats()["path"]
+    codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), cap, stream=stream)
+    path2 = ctx.last_encode_stats()["path"]
+    codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n, stream=stream)
+    torch.cuda.synchronize()
+    second_ms = (time.perf_counter() - t0) * 1e3
+    return {"first_call_ms": first_ms, "encode_path": path, "second_call_ms": second_ms, "second_encode_path": path2}
 
 
 def make_codec(A, ctx, codec_name, fidelity, block=0, ckpt=0, compact=False):
@@ -713,6 +798,18 @@ def main():
         cpu_all = all_cores_baseline(sample, kind, args.fidelity, block_ints)
         host_api = None if args.no_host_api else host_buffer_rates(codec, sample[:min(m, 64 * (1 << 20))])
 
+    # ---- two rows the steady-state headline hides (N = 1): the byte-for-byte drop-in mode and a geometry's first call
+    single_stream = first_call = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            single_stream = single_stream_row(torch, A, ctx, device, args.codec, args.fidelity, d_in)
+        except Exception as exc:  # noqa: BLE001
+            single_stream = {"error": repr(exc)}
+        try:
+            first_call = first_call_row(torch, ctx, codec, d_in, n, outs[0], cap, d_back, stream)
+        except Exception as exc:  # noqa: BLE001
+            first_call = {"error": repr(exc)}
+
     # ---- the other single-GPU BASELINE configs, a few steps each (N = 1 only)
     extra = None
     if rank == 0 and world == 1 and not args.no_extra:
@@ -720,7 +817,8 @@ def main():
         torch.cuda.empty_cache()
         extra = []
         rows = [("config 3a", "fold", 3, "zipf24s1.2", n), ("config 3b", "rfold", 3, "zipf24s1.2", n),
-                ("config 1 data shape", "fold", 1, "uniform1-256", n)]
+                ("config 1 data shape", "fold", 1, "uniform1-256", n),
+                ("ANSfold-5 on config 2 data (table_efficiency.cpp:176-179 runs fidelities 1 and 5)", "fold", 5, args.dist, n)]
         for label, cn, f, spec, m in rows:
             try:
                 r = run_single(torch, A, ctx, device, cn, f, spec, m, 3, 1,
@@ -789,30 +887,66 @@ def main():
             "predicted_step_ms_bound": max(link_ms / max(in_flight, 1) if rotate else link_ms, 0.0),
         }
     if rank == 0:
+        def brief(r):
+            """[Gints/s, HBM-roofline fraction of the dominant kernel] of one configuration row"""
+            if not r or "error" in r:
+                return None
+            rf = r.get("roofline") or {}
+            return [round(r["value"] / 1e3, 1), round(rf["frac"], 3) if rf.get("frac") is not None else None]
+
+        by_label = {}
+        for r in extra or []:
+            by_label[r.get("baseline_config", "")[:9]] = r
+        summary = {"cfg2": [round(value / 1e3, 1), round(roofline["frac"], 3) if roofline else None],
+                   "cfg3a": brief(by_label.get("config 3a")), "cfg3b": brief(by_label.get("config 3b")),
+                   "cfg1shape": brief(by_label.get("config 1 ")), "cfg5fb": brief(by_label.get("config 5 ")),
+                   "fold5": brief(by_label.get("ANSfold-5")),
+                   "single_stream_mints": round(single_stream["value"], 1) if single_stream and "value" in single_stream else None,
+                   "first_call_ms": round(first_call["first_call_ms"], 2) if first_call and "first_call_ms" in first_call else None,
+                   "enc_dec_gints": [round(gpu_rates["enc_mints"] / 1e3, 1), round(gpu_rates["dec_mints"] / 1e3, 1)] if gpu_rates else None,
+                   "unit": "[Gints/s encode+decode, roofline.frac of that config's dominant kernel]", "all_roundtrips_ok": None}
+        rts = [ok] + [r.get("roundtrip_ok") for r in (extra or []) if "error" not in r]
+        if single_stream and "roundtrip_ok" in single_stream:
+            rts.append(single_stream["roundtrip_ok"])
+        summary["all_roundtrips_ok"] = all(bool(x) for x in rts) and not any("error" in r for r in (extra or []))
+        # Everything bulky (per-kernel tables, the extra configurations in full, the frontier, the Table-10 rows, the
+        # compaction rows) goes to a side file and to stderr; the ONE stdout line stays short enough that a reader of its
+        # tail sees the whole of it, and ends with `summary`.
+        details = {"kernels": kernels, "extra_configs": extra, "frontier": frontier, "config1_table10": config1,
+                   "alphabet_compaction": compaction, "cpu_all_cores": cpu_all, "host_buffer_api": host_api,
+                   "single_stream": single_stream, "first_call": first_call, "gpu_rates": gpu_rates, "cpu_baseline_full": cpu,
+                   "roofline_full": roofline, "workspace_mb": ctx.workspace_bytes() / 1e6}
+        details_path = None
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            details_path = os.path.join("gpurun_out", "bench_details.json")
+            with open(os.path.join(ROOT, details_path), "w") as fh:
+                json.dump(details, fh, indent=1)
+        except OSError:
+            details_path = None
+        print(json.dumps({"bench_details": details}), file=sys.stderr)
+        if roofline:  # (the sources are sentences: the side file has them)
+            roofline = {k: v for k, v in roofline.items() if k not in ("traffic_source", "issue_floor_source")}
         line = {
             "metric": "encode+decode Mints/s (uint32), bit-exact vs CPU reference per block",
             "value": value, "unit": "Mints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 symbols / u64 ANS states (f64 only in model normalisation)",
+            "vs_baseline": None,
+            "dtype": "u32 symbols; ANS state carried as an exact f64 (integers below 2^53) in the encoder, u64 in the decoder",
             "data": "synthetic",
             "config": {"workload": "ANS%s-%d on %d uint32 per GPU, %s, blocks of %d ints, restart every %d"
                                    % (args.codec, args.fidelity, n, args.dist, block_ints,
                                       args.ckpt or A.DEFAULT_CKPT_INTERVAL),
-                       "ints_per_gpu": n, "distribution": args.dist, "codec": codec.name(),
-                       "alphabet_compaction": bool(args.compact or args.codec == "int"),
-                       "generator": "ansx_generate_dev (counter-based, seed %d, rank r draws indices [r n, (r+1) n))" % SEED,
-                       "block_ints": block_ints, "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL,
-                       "multi_gpu": multi_gpu},
-            "roundtrip_ok": ok, "merged_container_ok": merged_ok,
-            "compressed_bytes_per_int": c_bytes, "bits_per_int": 8 * c_bytes,
+                       "codec": codec.name(), "seed": SEED, "multi_gpu": multi_gpu},
+            "roundtrip_ok": ok, "merged_container_ok": merged_ok, "bits_per_int": 8 * c_bytes,
             "near_threshold_decisions": stats["near_threshold_decisions"], "encode_path": stats["path"],
-            "roofline": roofline, "cpu_baseline": cpu, "gpu_rates": gpu_rates, "cpu_all_cores": cpu_all,
-            "host_buffer_api": host_api, "kernels": kernels, "extra_configs": extra, "frontier": frontier,
-            "config1_table10": config1, "alphabet_compaction": compaction,
-            "workspace_mb": ctx.workspace_bytes() / 1e6,
+            "roofline": roofline,
+            "cpu_baseline": ({k: v for k, v in cpu.items() if k in ("value", "unit", "cores", "kind", "sample", "cpu", "enc_mints", "dec_mints", "bits_per_int")} if cpu else None),
+            "details": details_path,
         }
         if cpu:
             line["speedup_vs_cpu_1thread"] = value / cpu["value"]
+        line["summary"] = summary
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -174,10 +174,16 @@ int ansx_merge_containers_dev(ansx_ctx* ctx, const uint8_t* const* d_parts, cons
  * this library does not link it).  d_recv (root only): nranks * slot_bytes bytes, 16-byte aligned slots; a rank
  * container larger than slot_bytes fails the call on every rank (ANSX_ERR_CAPACITY).  *merged_bytes: size of the
  * merged container on the root, 0 elsewhere.  Blocks until the sizes are known; the transfers and the merge run on
- * `stream`. */
+ * `stream`.  slot_bytes is the ROOT's: it travels with the sizes, every rank checks every container against it and all
+ * ranks return the same ANSX_ERR_CAPACITY together (a non-root rank's own argument is ignored).  A non-root rank returns
+ * with its ncclSend queued on `stream`: d_container must stay untouched until that stream has been synchronised. */
 int ansx_gather_containers(ansx_ctx* ctx, void* nccl_comm, int rank, int nranks, int root, const uint8_t* d_container,
     size_t bytes, uint8_t* d_recv, size_t slot_bytes, uint8_t* d_merged, size_t merged_cap, size_t* merged_bytes,
     void* stream);
+
+/* Ranks of the communicator the context's most recent ansx_gather_containers call ran on, as RCCL itself reports them
+ * (ncclCommCount); 0 before the first call.  For bench lines / logs that must show N GPUs really took part. */
+int ansx_last_gather_ranks(const ansx_ctx* ctx);
 
 /* Parse + validate a container header held in HOST memory. */
 int ansx_container_info(const uint8_t* container, size_t bytes, ansx_container_header* out);
@@ -202,8 +208,10 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             per-block hash tables), 2 the same with the fused model kernel; + 16: a hint
  *                             did not hold and the call was repeated on the discovery path; + 32: a frame above
  *                             2^16 turned up in a call laid out for packed restart points and the call was
- *                             repeated with wide ones (remembered per geometry).  Either way the output
- *                             bytes are a function of the input and the options only. */
+ *                             repeated with wide ones (remembered per geometry, but only as the attempt to run
+ *                             FIRST); + 64: the remembered wide form was not needed by this input and the call was
+ *                             repeated with packed restart points.  Either way the output bytes -- the restart-point
+ *                             format included -- are a function of the input and the options only. */
 typedef struct {
     uint32_t max_nsyms;
     uint32_t max_log2_frame;

@@ -25,16 +25,19 @@ for d in sorted(glob.glob(os.path.join(out, "sq*"))):
     if not files:
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(files[0])):
         k = short(r["Kernel_Name"])
         if k.startswith("k_"):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[k].add(r.get("Dispatch_Id"))
     for k, v in acc.items():
         w = max(v.get("SQ_WAVES", 1.0), 1.0)
         for c, x in v.items():
             if c != "SQ_WAVES":
                 kern[k][c + "_per_wave"] = (4.0 if c in CYC else 1.0) * x / w
         kern[k]["waves"] = w
+        kern[k]["launches"] = max(1, len(disp[k]))
 for k, v in kern.items():
     wc = v.get("SQ_WAVE_CYCLES_per_wave")
     if wc:

@@ -4,6 +4,11 @@ import json
 import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+if d.get("details"):  # per-kernel tables and the extra configurations live in the side file since round 4
+    try:
+        d.update(json.load(open(d["details"])))
+    except OSError:
+        pass
 
 
 def show(e, label):

@@ -744,6 +744,58 @@ def test_corrupted_payload_never_faults(A, ctx):
             codec.decode(cont[:cut].copy() if cut else np.zeros(1, dtype=np.uint8), data.size)
 
 
+def test_crafted_index_is_rejected_not_dereferenced(A):
+    """the ring decode path skips k_validate_index and lets every parser check the two index entries of
+    its own block.  That check must not depend on a container field: a header with payload_bytes = 0 (once the marker of
+    single-stream mode) and a garbage index has to be a format error -- on a fresh context and on one that remembers the
+    honest header of the same shape -- never a read at cont + payload_offset + <attacker's 64-bit offset>."""
+    n, block = 3 * 16384 + 77, 16384
+    data = ol.gen_inputs("zipf20s1.2", n, seed=12)
+    for kind, f in ((ol.FOLD, 1), (ol.RFOLD, 1)):
+        c0 = A.Context(0)
+        codec = codec_for(A, c0, kind, f, block_ints=block, ckpt_interval=1024)
+        cont = codec.encode(data)
+        H = A.parse_container(cont)["header"]
+        assert np.array_equal(codec.decode(cont, n), data)  # (c0 now remembers this header)
+        # locate the field by value instead of trusting an offset: it is the only u64 in the header equal to payload_bytes
+        hdr64 = cont[:64].view("<u8")
+        idx = [i for i in range(8) if int(hdr64[i]) == int(H.payload_bytes)]
+        assert len(idx) == 1
+        pb_off = 8 * idx[0]
+        garbage = [0x7FFFFFFFFFFF0000, 1 << 62, 0xFFFFFFFFFFFFFFF0, 1 << 40]
+        variants = []
+        a = cont.copy()  # payload_bytes = 0, index untouched
+        a[pb_off:pb_off + 8] = 0
+        variants.append(a)
+        b = cont.copy()  # payload_bytes = 0 and a garbage index
+        b[pb_off:pb_off + 8] = 0
+        ix = b[64:64 + 8 * (H.nblocks + 1)].view("<u8")
+        for i in range(H.nblocks + 1):
+            ix[i] = garbage[i % len(garbage)]
+        variants.append(b)
+        c = cont.copy()  # honest payload_bytes, garbage index
+        ix = c[64:64 + 8 * (H.nblocks + 1)].view("<u8")
+        for i in range(1, H.nblocks):
+            ix[i] = garbage[i % len(garbage)]
+        variants.append(c)
+        d = cont.copy()  # payload_bytes too small for the block count
+        d[pb_off:pb_off + 8] = np.frombuffer(np.uint64(37 * H.nblocks).tobytes(), dtype=np.uint8)
+        variants.append(d)
+        for bad in variants:
+            for ctxx in (c0, A.Context(0)):
+                with pytest.raises(A.AnsxError) as e:
+                    codec_for(A, ctxx, kind, f, block_ints=block, ckpt_interval=1024).decode(bad, n)
+                assert e.value.status == 3  # ANSX_ERR_FORMAT
+                if ctxx is not c0:
+                    ctxx.close()
+        assert np.array_equal(codec.decode(cont, n), data)
+        # single-stream mode still decodes (its two index entries are the host's own)
+        ss = codec_for(A, c0, kind, f, block_ints=A.SINGLE_STREAM)
+        small = data[:5000]
+        assert np.array_equal(ss.decode(ss.encode(small), small.size), small)
+        c0.close()
+
+
 @pytest.mark.parametrize("kind,f", [(ol.FOLD, 1), (ol.RFOLD, 1), (ol.FOLD, 3)])
 def test_decoder_stream_modes(A, ctx, kind, f):
     """The block decoder reads the stream through per-quad LDS rings, a staged copy of the whole

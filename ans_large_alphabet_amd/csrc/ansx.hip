@@ -71,6 +71,7 @@ struct ansx_ctx {
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
     const u32* cur_force = nullptr;  // per-block frames decided by the host (resolve_near), device array, for the repeat of a call
     const u32* cur_src = nullptr;    // set by encode_general: the ints the model kernels saw (the input, or its remapped form)
+    bool used_pc = false;        // set by launch_lds_encoder: the producer / consumer encoder kernel ran in the call
     bool used_fast = false;      // set by encode_general: the call's model came from k_candidates / k_model_finish
     u32 cur_nt = 0;              // set by encode_dev: candidates per block for the fast model path of this call (0 = exact path)
     u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
@@ -91,6 +92,14 @@ struct ansx_ctx {
         u32 parse_stage_words = 0;    // ANSX_PARSE_STAGE_WORDS: 0 = default
         bool model_fused = false;     // ANSX_MODEL_FUSED: the single LDS-resident model kernel instead of the five tailored ones
         bool model_sync = false;      // ANSX_MODEL_SYNC: always discover the alphabet with the mid-call read-back
+        bool use_pc = false;          // ANSX_USE_PC: k_encode_pc (producer / consumer wave pairs) for calls whose grid fills the chip.  Off by default:
+                                      // measured EQUAL to k_encode<1> on the headline workload (0.708 vs 0.707 ms) -- the pair's 53 vector
+                                      // instructions per symbol fill the SIMD as the lone wave's 44 do
+        bool force_pc = false;        // ANSX_FORCE_PC: the pair kernel for every workgroup of 64 full blocks, however few (tests)
+        bool no_pc = false;           // ANSX_NO_PC: the LDS-table encoder as one wave per 16 blocks everywhere (k_encode<1>), no producer / consumer pairs
+        int decode_pair = 0;          // ANSX_DECODE_PAIR: "0"/unset auto, "never", "always" (k_decode_rank2: two blocks per workgroup)
+        u32 pair_lds_limit = 0;       // ANSX_DECODE_PAIR_LDS: auto uses the pair kernel up to this many bytes of LDS per workgroup (0: never --
+                                      // measured SLOWER than one block per workgroup, 0.77-0.79 vs 0.72 ms on the headline workload)
         u32 wide_at = 16;             // ANSX_TEST_WIDE_AT: frames above 2^this need wide restart points (tests lower it to force the repeat)
         bool wide_restart = false;    // ANSX_WIDE_RESTART: 36-byte restart points (the v2 form) in every container
         u32 ns_hint = 0;              // ANSX_NS_HINT: alphabet hint for every call (0 = learn per geometry)
@@ -365,6 +374,63 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
 // --------------------------------------------------------------------------------- encode
 constexpr int ANSX_RETRY_GENERAL = -1;  // internal: an optimistic assumption did not hold, repeat without it
 constexpr int ANSX_RETRY_WIDE = -2;     // internal: a frame above 2^16 in a call laid out for packed restart points, repeat with wide ones
+
+// K5, LDS-table form (frames <= 2^16, every block's alphabet <= ns_entries): the producer / consumer kernel k_encode_pc over the
+// leading workgroups of 64 full blocks, k_encode<1> over whatever is left (fewer than 64 blocks, the partial last block) or over
+// everything when the geometry rules the pair kernel out.  Returns false if the alphabet does not fit LDS at all (caller: MODE 2).
+static int launch_lds_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32* src, u32 ns_entries, ansx_blk* blk, u64 scr_stride,
+    u64* ck_state, u32* ck_off, u32* enc_sizes, unsigned long long* enc_gsums, u32 NB, hipStream_t s, bool* launched)
+{
+    *launched = false;
+    c->used_pc = false;
+    const u32 lds_stride = ns_entries | 1u;  // odd stride spreads the 16 tables over the banks
+    const size_t enc_lds = (size_t)16 * lds_stride * 4;
+    if (enc_lds > 40 * 1024) return ANSX_OK;
+    *launched = true;
+    const bool pow2 = map_is_pow2(g.map);
+    u32 first = 0;
+    // ---- producer / consumer pairs
+    const u32 rowwords = ((ns_entries + 2u) / 2u) | 1u;  // ns_entries + 1 running sums of 16 bits, an odd number of words per row
+    const size_t pc_lds = (size_t)64 * rowwords * 4 + (size_t)4 * 2 * ANSX_PC_S * 1024;
+    const u32 full_blocks = (u32)(g.n / g.block_ints);
+    const bool pc_ok = (c->dbg.use_pc || c->dbg.force_pc) && !c->dbg.no_pc && ns_entries <= 64u * ANSX_PC_MAXLD && pc_lds <= 160 * 1024 && g.block_ints % (16u * ANSX_PC_S * 2u) == 0
+        && (g.ckpt == 0 || g.ckpt % (4u * ANSX_PC_S) == 0) && (u64)scr_stride * 16 < 0x40000000ull && full_blocks >= 64
+        && ((full_blocks / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc);  // (a grid that leaves most CUs idle is better served by one wave per workgroup)
+    if (pc_ok) {
+        const u32 wgs = full_blocks / 64;
+        if (pow2) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode_pc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
+            LAUNCH(c, "k_encode", (k_encode_pc<true>), wgs, 512, pc_lds, s, src, g, NSP, (const u32*)c->tab32.p, ns_entries, rowwords, blk,
+                (u8*)c->scratch.p, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+        } else {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode_pc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
+            LAUNCH(c, "k_encode", (k_encode_pc<false>), wgs, 512, pc_lds, s, src, g, NSP, (const u32*)c->tab32.p, ns_entries, rowwords, blk,
+                (u8*)c->scratch.p, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+        }
+        first = wgs * 64;
+        c->used_pc = true;
+        if (first >= NB) return ANSX_OK;
+    }
+    // ---- one wave per 16 blocks.  Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves
+    // per workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
+    const u32 enc_waves = (NB - first + 15) / 16;
+    u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
+    wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
+    const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
+    if (wpw * enc_lds > 48 * 1024) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+    }
+    if (pow2)
+        LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
+            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
+    else
+        LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
+            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
+    return ANSX_OK;
+}
 
 // ns_cap == 0: discovery mode -- the largest alphabet / frame of the call are read back between the
 // model kernels and the encoder launch (one host round trip per candidate batch).
@@ -671,30 +737,14 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // alphabet / frame actually produced, read back above).
     u64* ck_state = P.plain ? nullptr : (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = P.plain ? nullptr : (u32*)(d_out + P.lay.ckoff_off);
-    const u32 lds_stride = max_ns | 1u;  // odd stride spreads the 16 tables over the banks
-    const size_t enc_lds = (size_t)16 * lds_stride * 4;
     // (its emitted-byte stores go through a buffer descriptor spanning the wave's 16 scratch slots:
     // 31-bit offsets)
     const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull && !test_fixup;
-    if (f64_ok && enc_lds <= 40 * 1024) {
-        // Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves per
-        // workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
-        const u32 enc_waves = (NB + 15) / 16;
-        u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
-        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
-        const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
-        if (wpw * enc_lds > 48 * 1024) {
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
-        }
-        if (map_is_pow2(g.map))
-            LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-                (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
-        else
-            LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-                (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+    bool lds_launched = false;
+    if (f64_ok) {
+        if ((rc = launch_lds_encoder(c, g, NSP, src, max_ns, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s, &lds_launched))) return rc;
+    }
+    if (lds_launched) {
     } else if (f64_ok && !c->dbg.encode_gtab16) {
         // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
         const u32 w2 = (NB + 15) / 16;
@@ -843,27 +893,12 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     }
     u64* ck_state = (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = (u32*)(d_out + P.lay.ckoff_off);
-    const u32 lds_stride = ns_cap | 1u;  // odd stride spreads the 16 tables over the banks
-    const size_t enc_lds = (size_t)16 * lds_stride * 4;
-    if (enc_lds <= 40 * 1024) {
-        // Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves per
-        // workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
-        const u32 enc_waves = (NB + 15) / 16;
-        u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
-        wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
-        const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
-        if (wpw * enc_lds > 48 * 1024) {
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
-        }
-        if (map_is_pow2(g.map))
-            LAUNCH(c, "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
-        else
-            LAUNCH(c, "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+    bool lds_launched = false;
+    {
+        int rcl;
+        if ((rcl = launch_lds_encoder(c, g, NSP, src, ns_cap, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s, &lds_launched))) return rcl;
+    }
+    if (lds_launched) {
     } else {
         const u32 w2 = (NB + 15) / 16;
         u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
@@ -1084,7 +1119,7 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
     if (rc == ANSX_OK && near_blocks != 0) rc = resolve_near(c, P, d_in, d_out, cap, out_bytes, s, &seen, &redecided);
     if (rc == ANSX_RETRY_WIDE) return rc;
     c->last.host_redecided = redecided;
-    c->last.path = path;
+    c->last.path = path | (c->used_pc ? 128u : 0u);
     c->last.max_nsyms = c->h_pin[ANSX_G_MAXNSYMS];
     c->last.max_log2_frame = c->h_pin[ANSX_G_MAXLOGM];
     c->last.near_threshold_decisions = near_blocks;
@@ -1222,6 +1257,19 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
         const int force = c->dbg.decode_mode;  // tests: 1 "ring" | 2 "staged"
         const bool use_ring = ring_ok && (force ? force == 1 : ring_pays);
         if (use_ring) {
+            // two blocks per workgroup, decoded in one instruction stream (k_decode_rank2): as long as four such workgroups
+            // still fit a CU's LDS; the container's last one or two blocks take the single-block code inside that kernel
+            const size_t lds2 = rup((size_t)(maxM >= 32 ? maxM / 32 : 1) * 16, 16) + 4 * rup((size_t)max_ep * 4, 16) + ANSX_DEC_SCRATCH + 2 * ring_lds;
+            const int pair = c->dbg.decode_pair;  // tests / experiments: 1 never, 2 always (LDS permitting)
+            if (pair != 1 && g.nblocks >= 2 && (pair == 2 ? lds2 <= 150 * 1024 : lds2 <= c->dbg.pair_lds_limit)) {
+                if (lds2 > 48 * 1024)
+                    HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank2<RF>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                LAUNCH(c, "k_decode", (k_decode_rank2<RF>), (g.nblocks + 1) / 2, threads, lds2, s, cont, g, NSP, boff,
+                    ck_state, ck_off, payload_off, d_out, maxM, max_ep, (u64)cont_bytes, (const u32*)c->dec_cum.p,
+                    (const uint4*)c->dec_info.p, gflags);
+                return ANSX_OK;
+            }
             const size_t lds = rs_tables + ring_lds;
             if (lds > 48 * 1024)
                 HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, true>,
@@ -1658,6 +1706,12 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_T_HINT")) c->dbg.t_hint = value ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_NO_FAST_MODEL")) c->dbg.no_fast_model = on;
     else if (!strcmp(name, "ANSX_WIDE_RESTART")) c->dbg.wide_restart = on;
+    else if (!strcmp(name, "ANSX_NO_PC")) c->dbg.no_pc = on;
+    else if (!strcmp(name, "ANSX_FORCE_PC")) c->dbg.force_pc = on;
+    else if (!strcmp(name, "ANSX_USE_PC")) c->dbg.use_pc = on;
+    else if (!strcmp(name, "ANSX_DECODE_PAIR"))
+        c->dbg.decode_pair = !value ? 0 : !strcmp(value, "never") ? 1 : !strcmp(value, "always") ? 2 : 0;
+    else if (!strcmp(name, "ANSX_DECODE_PAIR_LDS")) c->dbg.pair_lds_limit = (value && value[0]) ? (u32)strtoul(value, nullptr, 10) : 0u;
     else if (!strcmp(name, "ANSX_FORGET_HINTS")) {  // the next call of every geometry is a first call again (bench.py: first_call_ms)
         c->ns_hint.clear();
         c->rf_hint.clear();

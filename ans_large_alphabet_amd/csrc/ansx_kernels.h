@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     const ansx_enc_entry* __restrict__ table, const u32* __restrict__ tab32, u32 lds_stride,
     ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
     u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off, u32* __restrict__ sizes,
-    unsigned long long* __restrict__ gsums)
+    unsigned long long* __restrict__ gsums, u32 first_block = 0)
 {
     extern __shared__ u32 lds_tab[];
     // sizes[b] = bytes of block b's stream, gsums[b / 64] += them: what k_assemble needs to place a block without
@@ -1631,7 +1631,8 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     // phase compete for the CU's instruction fetch: four waves per workgroup land one per SIMD (0.94 -> 0.79 ms on
     // the headline workload) and a barrier per super-batch keeps them in step (-> 0.70 ms).
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (blockDim.x >> 6) + wv) * 16));  // first block of this wave (uniform)
+    // first block of this wave (uniform); first_block: the blocks before it belong to another launch (k_encode_pc)
+    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)(first_block + (blockIdx.x * (blockDim.x >> 6) + wv) * 16));
     u32* const wtab = lds_tab + wv * 16 * lds_stride;
     const u32 gt = wb0 * 4 + lane;
     const u32 b = gt >> 2, ql = gt & 3;
@@ -1841,7 +1842,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
                 double sd = L.sd;
                 u32 pcur = L.p;
                 // every block of the workgroup is a full one: the same number of super-batches for all its waves
-                const bool wg_sync = blockDim.x > 64 && (u64)(blockIdx.x + 1) * (blockDim.x >> 2) * g.block_ints <= g.n;
+                const bool wg_sync = blockDim.x > 64 && ((u64)first_block + (u64)(blockIdx.x + 1) * (blockDim.x >> 2)) * g.block_ints <= g.n;
                 while (gi) {
                     if (wg_sync) __syncthreads();
                     const u32 top = gi;
@@ -1979,7 +1980,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
             for (int j = 0; j < ANSX_ENC_U; j++) raw1[j] = tab.fetchp(f, xa[j], raw1l[j]);
         }
         // (waves of one workgroup stay in step, see the scheduled loop above)
-        const bool wg_sync2 = blockDim.x > 64 && (u64)(blockIdx.x + 1) * (blockDim.x >> 2) * g.block_ints <= g.n;
+        const bool wg_sync2 = blockDim.x > 64 && ((u64)first_block + (u64)(blockIdx.x + 1) * (blockDim.x >> 2)) * g.block_ints <= g.n;
         while (gi) {
             if (wg_sync2) __syncthreads();
             const u32 top = gi;  // this super-batch encodes groups top-1 ... top-XB
@@ -2076,6 +2077,289 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
     // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
     st_u64_unaligned(out + L.p + 8 * ql, tab.state(L) - Lb);
     if (ql == 0) publish_size(B, b, L.p + 32);
+}
+
+// ---- k_encode_pc: the LDS-table encoder as a producer / consumer pair of waves per 16 blocks --------------------
+// k_encode<1> runs ONE wave per SIMD (4 chains per block is all the parallelism the format gives) and that wave issues
+// an instruction every ~7 cycles: it is a lone in-order stream with its own LDS / VMEM waits, and a SIMD gives a lone wave
+// one vector instruction per ~5.1 cycles at best (tests/tools/ubench_valu2.hip: two waves share a SIMD at 4.3 cycles per
+// f64 / VOP3 instruction and 2.4 per 4-byte-encoded 32-bit one).  Of its 44 vector instructions per symbol only the state
+// chain and the byte emission depend on the state; the fold map, the table look-up and the reciprocal depend on the input
+// alone.  Here a second wave on the same SIMD (the PRODUCER, waves 4..7 of a 512-thread workgroup) does that part a batch
+// of S steps ahead and hands every (lane, step) 16 bytes through LDS:
+//     word 0, 1  1/F as an f64, under-estimated as in enc_tab<true>::getp, its two lowest mantissa bits replaced by k
+//                (the number of exception bytes; 3 * 2^-52 relative, far inside the (2^-39.01, 2^-38) deficit window)
+//     word 2     F | base << 16
+//     word 3     the exception bytes laid out for the stores: byte 0 = x & 0xFF, bits 16..31 = (x >> 8 (k & 1)) & 0xFFFF
+// and the CONSUMER (waves 0..3, same lanes = same chains) runs the state chain and the emission: 35 vector instructions
+// per symbol instead of 44, no LDS gathers, no input loads.  The tables are u16 RUNNING SUMS, one per symbol plus the
+// frame size (freq = next - current; two adjacent ds_read_u16 as before): half the LDS of the 4-byte entries, which is
+// what makes room for the hand-over buffers (2 x S x 1 KB per pair).  One workgroup barrier per batch; double-buffered.
+// Host-checked: every block of the workgroup is a full block, block_ints % (4 S * 4) == 0 (no tail, no leading
+// remainder), restart interval a multiple of 4 S; the other blocks of the call go to k_encode<1>.
+#define ANSX_PC_S 8
+#define ANSX_PC_MAXLD 12  // staging: table entries per lane (alphabets up to 64 * 12 symbols)
+__device__ __forceinline__ void pc_store_short_hi(u32 v, ansx_u32x4 rs, u32 voff)
+{
+    asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+template <bool POW2>
+__global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, ansx_geo g, u32 NSP,
+    const u32* __restrict__ tab32, u32 ns_cap, u32 rowwords, ansx_blk* __restrict__ blk, u8* __restrict__ scratch,
+    u64 scr_stride, u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off, u32* __restrict__ sizes,
+    unsigned long long* __restrict__ gsums)
+{
+    extern __shared__ u32 lds_pc[];
+    constexpr int S = ANSX_PC_S;
+    typedef __attribute__((address_space(3))) u16 lds_u16;
+    typedef __attribute__((address_space(3))) ansx_u32x4 lds_x4;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 pair = wv & 3u;
+    const bool producer = wv >= 4u;
+    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + pair) * 16));  // first block of this pair (uniform)
+    u32* const ptab = lds_pc + pair * 16 * rowwords;  // the pair's 16 rows of running sums (u16), rowwords words each
+    u32* const hand = lds_pc + 64 * rowwords + pair * (2 * S * 64 * 4);
+    {
+        // Both waves of a pair stage its tables, eight rows each, two rows per round with every load of a round in flight:
+        // cum[0] = 0, cum[s + 1] = base(s) + freq(s) mod 2^16 (the compact entries hold a valid base for absent symbols too;
+        // what lies beyond a block's own alphabet is never looked up)
+        const u32 r0 = producer ? 8u : 0u;
+        const u32 lim = ns_cap < NSP ? ns_cap : NSP;
+        for (u32 j = 0; j < 8; j += 2) {
+            const u32* row0 = tab32 + (u64)(wb0 + r0 + j) * NSP;
+            const u32* row1 = row0 + NSP;
+            u32 v0[ANSX_PC_MAXLD], v1[ANSX_PC_MAXLD];
+#pragma unroll
+            for (int i = 0; i < ANSX_PC_MAXLD; i++) {
+                const u32 e = lane + 64 * i;
+                v0[i] = e < lim ? row0[e] : 0u;
+                v1[i] = e < lim ? row1[e] : 0u;
+            }
+            lds_u16* c0 = (lds_u16*)(ptab + (r0 + j) * rowwords);
+            lds_u16* c1 = (lds_u16*)(ptab + (r0 + j + 1) * rowwords);
+#pragma unroll
+            for (int i = 0; i < ANSX_PC_MAXLD; i++) {
+                const u32 e = lane + 64 * i;
+                if (e < lim) {
+                    c0[e + 1] = (u16)((v0[i] >> 16) + (v0[i] & 0xFFFFu));
+                    c1[e + 1] = (u16)((v1[i] >> 16) + (v1[i] & 0xFFFFu));
+                }
+            }
+            if (lane == 0) {
+                c0[0] = 0;
+                c1[0] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    const u32 b = wb0 + (lane >> 2), ql = lane & 3u;
+    const u32 G = g.block_ints >> 2;   // groups of four per block
+    const u32 NBATCH = G / (u32)S;
+    if (producer) {
+        // ---------------------------------------------------------------- producer
+        const ansx_map f = g.map;
+        const u64 iba = (u64)(uintptr_t)(in + (u64)wb0 * g.block_ints);
+        const ansx_u32x4 irs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)iba),
+            (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(16u * g.block_ints * 4u), 0x00020000u };
+        // byte offset of group (G - 32), this lane's state, in that view; a group before the block's first one gives an offset
+        // inside the previous block or beyond num_records (reads 0): never consumed
+        u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (G - ANSX_ENC_XB);
+        u32 xa[ANSX_ENC_XB];
+#ifndef ANSX_PC_ABL_NOLOAD
+#define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
+#else
+#define ANSX_XLOAD(dst, voff, j) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(dst) : "v"(lane) : "memory")
+#endif
+#pragma unroll
+        for (int j = 0; j < ANSX_ENC_XB; j++) {
+            xa[j] = j * 17 + lane;
+            ANSX_XLOAD(xa[j], vcur, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < ANSX_ENC_XB; i += 8)
+            asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
+                         "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
+        const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)ptab + 4 * (lane >> 2) * rowwords;
+        const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
+        const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
+        u32 pb = 0;  // batch being produced
+        for (u32 sb = 0; sb < G / ANSX_ENC_XB; sb++) {
+            const u32 vnext = vcur - 16 * ANSX_ENC_XB;
+#pragma unroll
+            for (int t = 0; t < ANSX_ENC_XB / S; t++) {
+                // the eight registers the previous batch released take the inputs of their steps in the next super-batch (the
+                // last eight of THIS one when requested at step 0, which they hold already)
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    const int e = (t * S + ANSX_ENC_XB - S + i) % ANSX_ENC_XB;
+                    if (t == 0) ANSX_XLOAD(xa[e], vcur, e);
+                    else ANSX_XLOAD(xa[e], vnext, e);
+                }
+                // this batch's registers were requested three requests ago: 3 x S younger loads are in flight
+                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                static_assert(S == 8, "the wait above counts three requests of eight loads");
+#pragma unroll
+                for (int i = 0; i < S; i++) asm volatile("" : "+v"(xa[t * S + i]));
+                u32 kk[S], shh[S], cur[S], nxt[S];
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    const u32 x = xa[t * S + i];
+                    if constexpr (POW2) {
+                        const u32 d = __builtin_elementwise_sub_sat(c32f, ffbh_u32(x));
+                        kk[i] = d >> 3;
+                        shh[i] = d & 0x18u;
+                    } else {
+                        kk[i] = map_nbytes(f, x);
+                        shh[i] = kk[i] << 3;
+                    }
+                    const u32 la = tbase + 2 * (__umul24(kk[i], f.D) + (x >> shh[i]));
+                    cur[i] = *(lds_u16*)(size_t)la;
+                    nxt[i] = *(lds_u16*)(size_t)(la + 2);
+                }
+                const u32 hb = hbase + (pb & 1u) * (S * 1024);
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    const u32 x = xa[t * S + i];
+                    const u32 F = (nxt[i] - cur[i]) & 0xFFFFu;
+                    const double Fd = (double)F;
+                    // 1/F, under-estimated on purpose (enc_tab<true>::getp)
+                    const double r0 = __builtin_amdgcn_rcp(Fd);
+                    const double rc = __builtin_fma(__builtin_fma(-Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
+                    ansx_u32x4 h;
+                    h.x = (f64_lo(rc) & ~3u) | kk[i];
+                    h.y = f64_hi(rc);
+                    h.z = F | (cur[i] << 16);
+                    const u32 xs = x >> (shh[i] & 8u);
+                    h.w = (x & 0xFFu) | (xs << 16);
+                    *(lds_x4*)(size_t)(hb + i * 1024) = h;
+                }
+                pb++;
+                __syncthreads();
+            }
+            vcur = vnext;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < ANSX_ENC_XB; i += 8)
+            asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
+                         "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
+#undef ANSX_XLOAD
+        return;
+    }
+    // -------------------------------------------------------------------- consumer
+    ansx_blk* B = &blk[b];
+    // a block without a model (an error, an unresolved model, a one-value block of the compaction layer) goes through the
+    // motions with every store out of range and publishes its special size at the end
+    const bool skip = B->status || !B->resolved || B->pa_sigma == 1;
+    const u32 logM = B->logM;
+    const u64 Lb = (u64)16 << logM;
+    const double Md = (double)(1u << logM);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        scratch + (u64)wb0 * scr_stride, 0, (int)(16 * scr_stride), 0x00020000);
+    const u64 sba = (u64)(uintptr_t)(scratch + (u64)wb0 * scr_stride);
+    const ansx_u32x4 srs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)sba), (u32)__builtin_amdgcn_readfirstlane((u32)(sba >> 32) & 0xFFFFu),
+        (u32)__builtin_amdgcn_readfirstlane((u32)(16 * scr_stride)), 0x00020000u };
+    const u32 obase = (u32)((lane >> 2) * scr_stride);
+    u8* out = scratch + (u64)b * scr_stride;
+    const u32 cg = g.ckpt >> 2;  // groups per restart interval (0 = none)
+    u32 ck_seg = (cg && G && !skip) ? (G - 1) / cg : 0;  // next restart point to record: segment index
+    u32 ck_g = ck_seg * cg;                               // ... and its group index
+    const u32 pbias = obase;
+    double sd = (double)Lb;
+    u32 pcur = skip ? 0x40000000u : B->prelude_bytes + obase;
+    auto record = [&](u32 gidx) {
+        // every symbol with index >= 4*gidx is now encoded: decoder restart point of segment ck_seg (as in k_encode)
+        if (ck_seg && gidx == ck_g) {
+            const u64 idx = (u64)b * g.nckf + (ck_seg - 1);
+            const u64 stv = f64_to_u64_exact(sd);
+            if (g.ckw) {
+                ckpt_state[idx * 4 + ql] = stv;
+                if (ql == 0) ckpt_off[idx] = pcur - pbias;
+            } else {
+                u8* rec = (u8*)ckpt_state + idx * ANSX_CK_RECORD;
+                const u64 pst = ((u64)quad_perm<ANSX_QP(1, 0, 3, 2)>((u32)(stv >> 32)) << 32) | quad_perm<ANSX_QP(1, 0, 3, 2)>((u32)stv);
+                if ((ql & 1u) == 0) {
+                    u8* pp = rec + 13u * (ql >> 1);
+                    st_u64_unaligned(pp, (stv & ((1ull << ANSX_CK_STATE_BITS) - 1ull)) | (pst << ANSX_CK_STATE_BITS));
+                    st_u32_unaligned(pp + 8, (u32)(pst >> 12));
+                    pp[12] = (u8)(pst >> 44);
+                }
+                if (ql == 0) {
+                    const u32 cur = pcur - pbias;
+                    st_u16_unaligned(rec + 26, (u16)cur);
+                    rec[28] = (u8)(cur >> 16);
+                }
+            }
+            ck_seg--;
+            ck_g -= cg;
+        }
+    };
+    const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
+    const u32 four_pos = 4u << (8 * ql), lomask = (1u << (8 * ql)) - 1u, ql8 = 8 * ql;
+    u32 gi = G;
+    for (u32 cb = 0; cb < NBATCH; cb++) {
+        __syncthreads();
+        const u32 hb = hbase + (cb & 1u) * (S * 1024);
+        ansx_u32x4 h[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) h[i] = *(lds_x4*)(size_t)(hb + i * 1024);
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            // the arithmetic form of the table entry (stage B of k_encode, minus the reciprocal)
+            const u32 k = h[i].x & 3u;
+            const double rcp = __builtin_bit_cast(double, ((u64)h[i].y << 32) | h[i].x);
+            const double Fd = (double)(h[i].z & 0xFFFFu);
+            const double based = (double)(h[i].z >> 16);
+            const u32 thr_hi = f64_hi(Fd) + (36u << 20);  // 2^36 * freq: same mantissa, low word 0
+            const double MF = Md - Fd, omF = 1.0 - Fd;
+            const u32 off1 = (h[i].x << 31) + ANSX_BUF_OOB;  // 0 when k is odd
+            const u32 off2 = (k - 2u) & 0x80000001u;          // k & 1 when k >= 2
+            // state chain (enc_update_n / the scheduled loop of k_encode)
+            const bool rn = f64_hi(sd) >= thr_hi;
+            const u32 w = f64_lo(sd + 4503599627370496.0);
+            int ex = rn ? -32 : 0;
+            asm("" : "+v"(ex));
+            const double s0 = __builtin_trunc(__builtin_ldexp(sd, ex));
+            const double q = __builtin_trunc(s0 * rcp);
+            const double base2 = __builtin_fma(q, MF, s0 + based);
+            const double one_short = __builtin_fmin(__builtin_fmax(__builtin_fma(-q, Fd, s0 + omF), 0.0), 1.0);
+            sd = __builtin_fma(one_short, MF, base2);
+            // byte emission
+            const u32 v = (k << ql8) + (rn ? four_pos : 0u);
+            const u32 s1 = quad_add_dpp<0xB1>(v);
+            const u32 Sq = quad_add_dpp<0x4E>(s1);
+            const u32 a = __builtin_amdgcn_sad_u8(Sq & lomask, 0u, pcur);
+            pcur = __builtin_amdgcn_sad_u8(Sq, 0u, pcur);
+#ifndef ANSX_PC_ABL_NOSTORE  // (timing-only ablations, never built into the product: -DANSX_PC_ABL_*)
+            __builtin_amdgcn_raw_buffer_store_b8((u8)h[i].w, rsrc, a + off1, 0, 0);
+            pc_store_short_hi(h[i].w, srs, a + off2);
+            __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, rn ? a + k : ANSX_BUF_OOB, 0, 0);
+#else
+            asm volatile("" :: "v"(a + off1), "v"(a + off2), "v"(rn ? a + k : ANSX_BUF_OOB), "v"(w));
+#endif
+        }
+        gi -= (u32)S;
+        record(gi);
+    }
+    if (skip) {
+        if (ql == 0) {
+            const u32 sz = (B->pa_sigma == 1 && !B->status) ? B->pre_bytes : 0u;
+            B->stream_bytes = sz;
+            sizes[b] = sz;
+            if (sz) atomicAdd(&gsums[b >> 6], (unsigned long long)sz);
+        }
+        return;
+    }
+    // flush state - L, order 0,1,2,3 (ans_fold.hpp:275-278,115-120)
+    const u32 pfin = pcur - pbias;
+    st_u64_unaligned(out + pfin + 8 * ql, f64_to_u64_exact(sd) - Lb);
+    if (ql == 0) {
+        const u32 sz = pfin + 32;
+        B->stream_bytes = sz;
+        sizes[b] = sz;
+        atomicAdd(&gsums[b >> 6], (unsigned long long)sz);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3191,91 +3475,24 @@ __device__ __forceinline__ void dec_stage_stream(u32* lds_stream, const u8* __re
     if (tid < 2) lds_stream[nw + 2 + tid] = 0;
 }
 
-// ---- K8: one workgroup per block.  Builds the decoder tables, then one quad of lanes per segment
-// decodes forward from its restart point, reading the stream through per-quad LDS rings (RING),
-// a staged copy of the whole block stream, or straight from HBM (partial block / no room).
-// (History on MI355X, 256 Mi ints, with the original slot->symbol tables: no staging 1.56 ms;
-// whole-stream staging 1.38 ms; a ring with compiler-managed waits 1.62 ms -- every refill drained
-// the output stores.  With rank/select tables and the hand-counted vmcnt(4) ring: 0.73 ms.)
-//
-// k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
-// RING: per-quad stream rings instead of the staged stream (stream_cap is then the container size).
-template <bool RFOLD, bool RING>
-__global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
-    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
-    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
-    u32 max_ns, u64 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
-    u32* __restrict__ gflags)
+// The rank/select decoder tables of one block, built by the whole workgroup (nt threads) from its parsed inc[] row.
+// Frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1), compaction of the
+// present symbols, running base, start-of-symbol bitmap: one packed exclusive scan per nt symbols (frequency in the low
+// word, presence in the high word) gives every present symbol its base and its rank.  The inc[] values of four rounds
+// are requested together, so a block pays one global round trip per 4 nt symbols (one wave doing 64 symbols per round
+// with the loads inside the round was most of this kernel's time on 2300-symbol alphabets); the first four rounds'
+// values arrive in cur4 / prv4 (requested by the caller before anything else was waited for).
+// Bitmap entry w = {bitmap word, biased prefix} sits at bw[w * WSTRIDE + WOFF] (.x) and + 1 (.y): WSTRIDE 2 is the
+// one-block layout (uint2 array), WSTRIDE 4 interleaves the entries of TWO blocks (WOFF 0 / 2) so that both are
+// addressed by the same register with an immediate offset (k_decode_rank2).  The caller has zeroed the .x words and
+// sh_bad and synchronised.  Returns false (after a workgroup barrier) if the row is not a valid table.
+template <bool RFOLD, u32 WSTRIDE, u32 WOFF>
+__device__ __forceinline__ bool dec_build_rank_tables(const ansx_geo& g, u32* bw, uint2* ep, u64* sh_scan, u32* sh_bad,
+    const u32* __restrict__ gc, u32 (&cur4)[4], u32 (&prv4)[4], u32 ns, u32 M, u32 W, u32 max_ns, u32 rflag,
+    const u8* __restrict__ stream, u32 tid, u32 nt, u32* __restrict__ gflags)
 {
-    // (no static LDS in this kernel: the bitmap table sits at LDS address 0, so its reads need no base added)
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const u32 tid = threadIdx.x, nt = blockDim.x;
-    const u32 b = blockIdx.x;
-    // Everything the table build needs from HBM is requested before anything is waited for: the block's parse
-    // results, its stream bounds and the first 4 nt parsed inc[] values (a row of g_cum has NSP + 8 entries
-    // whatever the block's alphabet; values beyond it are masked below) -- one round trip instead of three.
-    const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
-    u32 cur4[4], prv4[4];
-#pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-        const u32 s = q * nt + tid;
-        cur4[q] = s < NSP ? gc[s + 1] : 0u;
-        prv4[q] = (s < NSP && s) ? gc[s] : 0u;
-    }
-    const uint4 bi = binfo[b];
-    const u64 boff = block_off[b], boff1 = block_off[b + 1];
-    if (bi.w) return;  // parse error already flagged
-    const u32 ns = bi.x, logM = bi.y, rflag = bi.z;
-    const u32 nb = geo_block_n(g, b);
-    const u8* stream = cont + payload_off + boff;
-    const u32 sbytes = (u32)(boff1 - boff);
     const ansx_map f = g.map;
     const u32 T = fold_T(g.f);
-    const u32 M = 1u << logM;
-    // LDS carve: [bitmap+prefix][entries][symbol ids][most-frequent table][staged stream]
-    const u32 wmax = maxM >= 32 ? maxM / 32 : 1;
-    u32 off = 0;
-    uint2* bwp = (uint2*)(smem + off);
-    off += (wmax * 8 + 15) & ~15u;
-    uint2* ep = (uint2*)(smem + off);
-    off += 2 * ((max_ns * 4 + 15) & ~15u);  // (same bytes as the host's 2 x rup(4 max_ns, 16))
-    u64* sh_scan = (u64*)(smem + off);        // 9 words of scan scratch + the block's error flag (ANSX_DEC_SCRATCH bytes)
-    u32& sh_bad = *(u32*)(smem + off + 80);
-    off += ANSX_DEC_SCRATCH;
-    u32* lds_stream = (u32*)(smem + off);
-    const u32 W = M >= 32 ? M / 32 : 1;
-    // full block: all segments have g.ckpt ints (host-checked), each quad's first one is requested now
-    const bool use_ring = RING && nb == g.block_ints;
-    dec_ring_desc D;
-    dec_ring_pre RP;
-    if (use_ring) {
-        // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
-        // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
-        const u64 sabs = payload_off + boff;  // stream offset inside the container
-        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
-        const u8* base = cont + (sabs - (u64)D.backoff);
-        u64 span = (u64)D.backoff + sbytes + 64;
-        const u64 room = stream_cap - (sabs - (u64)D.backoff);  // container bytes from base on
-        if (span > room) span = room;
-        const u64 ba = (u64)(uintptr_t)base;
-        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
-        dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
-    }
-    for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
-    if (tid == 0) {
-        sh_bad = 0;
-        // dec_lut_rank::get addresses the bitmap table from LDS address 0
-        if ((u32)(size_t)(__attribute__((address_space(3))) void*)bwp != 0u) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
-    }
-    const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
-    if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
-    __syncthreads();
-    // Frequencies from the parsed inc[] (ans_util.hpp:33-41: nfreq[s] = inc[s]-inc[s-1]-1), compaction of the
-    // present symbols, running base, start-of-symbol bitmap -- by the whole workgroup, nt symbols per round:
-    // one packed exclusive scan (frequency in the low word, presence in the high word) gives every present
-    // symbol its base and its rank.  The inc[] values of four rounds are requested together, so a block
-    // pays one global round trip per 4 nt symbols (one wave doing 64 symbols per round with the loads
-    // inside the round was most of this kernel's time on 2300-symbol alphabets).
     {
         u64 carry = 0;
         u32 bad = 0;
@@ -3321,7 +3538,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
                         u32 mfv = 0;
                         if (RFOLD && rflag && s < T) mfv = ld_u32_unaligned(stream + 4 + 4 * (u64)s);
                         ep[r] = make_uint2((base << 16) | fr, dec_make_pv(f, s, RFOLD && rflag, T, mfv));
-                        atomicOr(&bwp[base >> 5].x, 1u << (base & 31));
+                        atomicOr(&bw[(base >> 5) * WSTRIDE + WOFF], 1u << (base & 31));
                     } else {
                         bad = 1;
                     }
@@ -3335,32 +3552,112 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         }
         if ((carry & 0xFFFFFFFFull) != M || (carry >> 32) > max_ns) bad = 1;
         if (bad) {
-            sh_bad = 1;
+            *sh_bad = 1;
             atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
         }
     }
     __syncthreads();
-    if (sh_bad) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the prefetched window is still on its way)
-        return;
-    }
+    if (*sh_bad) return false;
     if (tid < 64) {  // running popcount before every bitmap word
         const u32 per = (W + 63) / 64;
         const u32 lo = tid * per;
         u32 loc = 0;
         for (u32 i = 0; i < per; i++)
-            if (lo + i < W) loc += (u32)__builtin_popcount(bwp[lo + i].x);
+            if (lo + i < W) loc += (u32)__builtin_popcount(bw[(lo + i) * WSTRIDE + WOFF]);
         const u32 incl = wave_incl_scan(loc);
-        dec_lut_rank bl;
-        bl.ep = ep;
-        u32 run = incl - loc + bl.bias();
+        // (the second word of a bitmap entry: set bits before it - 1 + (LDS byte address of ep) / 8, see dec_lut_rank)
+        u32 run = incl - loc + ((u32)(size_t)(__attribute__((address_space(3))) const void*)ep / 8u - 1u);
         for (u32 i = 0; i < per; i++)
             if (lo + i < W) {
-                bwp[lo + i].y = run;
-                run += (u32)__builtin_popcount(bwp[lo + i].x);
+                bw[(lo + i) * WSTRIDE + WOFF + 1] = run;
+                run += (u32)__builtin_popcount(bw[(lo + i) * WSTRIDE + WOFF]);
             }
     }
     __syncthreads();
+    return true;
+}
+
+// ---- K8: one workgroup per block.  Builds the decoder tables, then one quad of lanes per segment
+// decodes forward from its restart point, reading the stream through per-quad LDS rings (RING),
+// a staged copy of the whole block stream, or straight from HBM (partial block / no room).
+// (History on MI355X, 256 Mi ints, with the original slot->symbol tables: no staging 1.56 ms;
+// whole-stream staging 1.38 ms; a ring with compiler-managed waits 1.62 ms -- every refill drained
+// the output stores.  With rank/select tables and the hand-counted vmcnt(4) ring: 0.73 ms.)
+//
+// k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
+// RING: per-quad stream rings instead of the staged stream (stream_cap is then the container size).
+template <bool RFOLD, bool RING>
+__global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
+    u32 max_ns, u64 stream_cap, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
+    u32* __restrict__ gflags)
+{
+    // (no static LDS in this kernel: the bitmap table sits at LDS address 0, so its reads need no base added)
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 b = blockIdx.x;
+    // Everything the table build needs from HBM is requested before anything is waited for: the block's parse
+    // results, its stream bounds and the first 4 nt parsed inc[] values (a row of g_cum has NSP + 8 entries
+    // whatever the block's alphabet; values beyond it are masked below) -- one round trip instead of three.
+    const u32* gc = g_cum + (u64)b * (NSP + 8);  // gc[s+1] = inc[s]
+    u32 cur4[4], prv4[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+        const u32 s = q * nt + tid;
+        cur4[q] = s < NSP ? gc[s + 1] : 0u;
+        prv4[q] = (s < NSP && s) ? gc[s] : 0u;
+    }
+    const uint4 bi = binfo[b];
+    const u64 boff = block_off[b], boff1 = block_off[b + 1];
+    if (bi.w) return;  // parse error already flagged
+    const u32 ns = bi.x, logM = bi.y, rflag = bi.z;
+    const u32 nb = geo_block_n(g, b);
+    const u8* stream = cont + payload_off + boff;
+    const u32 sbytes = (u32)(boff1 - boff);
+    const u32 M = 1u << logM;
+    // LDS carve: [bitmap+prefix][entries][symbol ids][most-frequent table][staged stream]
+    const u32 wmax = maxM >= 32 ? maxM / 32 : 1;
+    u32 off = 0;
+    uint2* bwp = (uint2*)(smem + off);
+    off += (wmax * 8 + 15) & ~15u;
+    uint2* ep = (uint2*)(smem + off);
+    off += 2 * ((max_ns * 4 + 15) & ~15u);  // (same bytes as the host's 2 x rup(4 max_ns, 16))
+    u64* sh_scan = (u64*)(smem + off);        // 9 words of scan scratch + the block's error flag (ANSX_DEC_SCRATCH bytes)
+    u32& sh_bad = *(u32*)(smem + off + 80);
+    off += ANSX_DEC_SCRATCH;
+    u32* lds_stream = (u32*)(smem + off);
+    const u32 W = M >= 32 ? M / 32 : 1;
+    // full block: all segments have g.ckpt ints (host-checked), each quad's first one is requested now
+    const bool use_ring = RING && nb == g.block_ints;
+    dec_ring_desc D;
+    dec_ring_pre RP;
+    if (use_ring) {
+        // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
+        // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
+        const u64 sabs = payload_off + boff;  // stream offset inside the container
+        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
+        const u8* base = cont + (sabs - (u64)D.backoff);
+        u64 span = (u64)D.backoff + sbytes + 64;
+        const u64 room = stream_cap - (sabs - (u64)D.backoff);  // container bytes from base on
+        if (span > room) span = room;
+        const u64 ba = (u64)(uintptr_t)base;
+        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
+        dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
+    }
+    for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
+    if (tid == 0) {
+        sh_bad = 0;
+        // dec_lut_rank::get addresses the bitmap table from LDS address 0
+        if ((u32)(size_t)(__attribute__((address_space(3))) void*)bwp != 0u) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+    }
+    const bool st_lds = !RING && (sbytes + 24 <= stream_cap);
+    if (st_lds) dec_stage_stream(lds_stream, stream, sbytes, tid, nt);
+    __syncthreads();
+    if (!dec_build_rank_tables<RFOLD, 2, 0>(g, (u32*)bwp, ep, sh_scan, &sh_bad, gc, cur4, prv4, ns, M, W, max_ns, rflag, stream, tid, nt, gflags)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the prefetched window is still on its way)
+        return;
+    }
     dec_lut_rank lut;
     lut.bwp = bwp;
     lut.ep = ep;
@@ -3374,6 +3671,349 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else
         dec_segments<false>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
+}
+
+// ---- k_decode_rank2: TWO blocks per workgroup, their segments decoded in ONE instruction stream ---------------
+// A decoder step is a dependent chain (slot -> bitmap word -> entry -> multiply -> renormalise? -> quad sum -> stream
+// window -> next slot: ~22 vector instructions and three LDS round trips, ~500 cycles for a wave alone), and what a wave
+// waits for inside it is not free for the other waves of its SIMD: an instruction that depends on the one before it
+// holds the vector pipe for ~8.4 cycles instead of ~4.3 (tests/tools/ubench_valu2.hip, "dependent f64 chain": the wave
+// beside it gets one issue per ~8 cycles).  k_decode_rank runs 10 such single-chain waves per CU and saturates at about
+// half the issue rate.  Here every lane carries the states of two segments -- segment i of block 2w and segment i of
+// block 2w + 1 -- and the two steps are written into one basic block, so that consecutive instructions belong to
+// different chains; the LDS per block is what it was (two tables, two sets of rings: five workgroups per CU instead of
+// ten, the same blocks in flight).  The bitmap entries of the two blocks are interleaved (16 bytes per 32 slots:
+// {word A, prefix A, word B, prefix B}) so that both tables are addressed from LDS address 0 by the same shift, block B
+// through the instruction's immediate offset.
+template <u32 OFF>
+struct dec_lut_rank2 {
+    static constexpr bool WIDE = false;
+    static constexpr u32 OFFSET = OFF;
+    __device__ __forceinline__ void get(u32 slot, u32& fr, u32& base, u32& pv) const
+    {
+        const u64 wpw = *(__attribute__((address_space(3))) const u64*)(size_t)(((slot >> 1) & 0x7FF0u) + OFF);
+        const uint2 wp = make_uint2((u32)wpw, (u32)(wpw >> 32));
+        const u32 r8 = (u32)__builtin_popcount(wp.x << (~slot & 31u)) + wp.y;
+        const u64 e = *(__attribute__((address_space(3))) const u64*)(size_t)(r8 << 3);  // one 8-byte LDS read
+        pv = (u32)(e >> 32);
+        fr = (u32)e & 0xFFFFu;
+        base = (u32)e >> 16;
+    }
+};
+
+// one segment's decoder state with its stream ring (the body of dec_segments_ring, as an object, so that two of them
+// can be advanced in turn)
+template <typename LUT>
+struct dec_ring_chain {
+    static constexpr int RB = ANSX_RING_BYTES, CHK = ANSX_RING_CHK, R = 32 * CHK, NP = CHK / 2, T = RB - R - 16;
+    u64 st, Lb;
+    u32 q, logM, mask;
+    int lo, lane_off;
+    bool pending;
+    ansx_u32x4 rr[NP];
+    u32* ring;
+    u8* ring8;
+    u32* op;
+    dec_ring_desc D;
+    LUT lut;
+    __device__ __forceinline__ void setup(u32* rings, u32 quad, u32 ql, u32 logM_, const dec_ring_desc& D_)
+    {
+        ring = rings + quad * (ANSX_RING_STRIDE / 4);
+        ring8 = (u8*)ring;
+        logM = logM_;
+        mask = (1u << logM_) - 1;
+        Lb = (u64)16 << logM_;
+        lane_off = (R / 4) * (int)ql;
+        D = D_;
+    }
+    // the quad's restart point and initial window as requested by dec_ring_prefetch (first segment) ...
+    __device__ __forceinline__ void begin(const dec_ring_pre& P, ansx_u32x4 (&r)[RB / 64])
+    {
+        st = P.st;
+        lo = P.lo;
+        q = ANSX_DEC_Q(P.p);
+#pragma unroll
+        for (int j = 0; j < RB / 64; j++) r[j] = P.r[j];
+    }
+    // ... or requested now (further segments of the same quad)
+    __device__ __forceinline__ void begin(const ansx_geo& g, u32 b, u32 seg, u32 ql, u32 sbytes, const u64* __restrict__ ckpt_state,
+        const u32* __restrict__ ckpt_off, ansx_u32x4 (&r)[RB / 64])
+    {
+        const u64 idx = (u64)b * g.nckf + (seg - 1);
+        u32 po;
+        ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &st, &po);
+        const int p = (int)(po < sbytes ? po : sbytes);
+        lo = (p - T) & ~(R / 4 - 1);
+        q = ANSX_DEC_Q(p);
+#pragma unroll
+        for (int j = 0; j < RB / 64; j++) r[j] = ring_load16(D, lo + (RB / 4) * (int)ql + 16 * j, true);
+    }
+    __device__ __forceinline__ void fill(ansx_u32x4 (&r)[RB / 64], u32 ql)  // (behind the caller's vmcnt(0))
+    {
+#pragma unroll
+        for (int j = 0; j < RB / 64; j++) {
+            asm volatile("" : "+v"(r[j]));
+            const u32 d = (u32)(lo + (RB / 4) * (int)ql + 16 * j) & (RB - 1);
+            *(ansx_u32x4*)(ring8 + d) = r[j];
+            if (d == 0) *(uint2*)(ring8 + RB) = make_uint2(r[j].x, r[j].y);  // second copy of ring bytes 0..7
+        }
+        pending = false;
+#pragma unroll
+        for (int j = 0; j < NP; j++) rr[j] = ansx_u32x4{ 0u, 0u, 0u, 0u };
+    }
+    __device__ __forceinline__ void land()
+    {
+        if (pending) {
+            lo -= R;
+            const u32 d0 = (u32)(lo + lane_off) & (RB - 1);
+#pragma unroll
+            for (int j = 0; j < NP; j++) *(ansx_u32x4*)(ring8 + d0 + 16 * j) = rr[j];
+            if (d0 == 0) *(uint2*)(ring8 + RB) = make_uint2(rr[0].x, rr[0].y);
+        }
+    }
+    __device__ __forceinline__ void request()
+    {
+        const int cur = ANSX_DEC_P(q);
+        pending = (cur - lo) < T;
+#pragma unroll
+        for (int j = 0; j < NP; j++) rr[j] = ring_load16(D, lo - R + lane_off + 16 * j, pending);
+    }
+    __device__ __forceinline__ void keep()  // the request's registers stay live behind the caller's wait
+    {
+        if constexpr (NP == 2) asm volatile("" : "+v"(rr[0]), "+v"(rr[1]));
+        else asm volatile("" : "+v"(rr[0]));
+    }
+    __device__ __forceinline__ u32 step(const dec_quad_const& qc)
+    {
+        return dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, (const u8*)nullptr, ring);
+    }
+    // The same step (dec_step, rank/select table, ring stream) cut at its three LDS round trips, so that the caller can
+    // alternate the stages of two chains: every stage ends by ISSUING its LDS reads, the next one starts by using them.
+    u32 t_slot, t_sh, t_pv, t_nlo, t_nhi;
+    u64 t_wpw, t_e, t_qs;
+    u32 t_w0, t_w1, t_w2;
+    bool t_rn;
+    __device__ __forceinline__ void s1()  // slot -> bitmap entry
+    {
+        t_slot = (u32)st & mask;
+        t_wpw = *(__attribute__((address_space(3))) const u64*)(size_t)(((t_slot >> 1) & 0x7FF0u) + LUT::OFFSET);
+        t_qs = st >> logM;
+    }
+    __device__ __forceinline__ void s2()  // rank -> the symbol's entry
+    {
+        const u32 r8 = (u32)__builtin_popcount((u32)t_wpw << (~t_slot & 31u)) + (u32)(t_wpw >> 32);
+        t_e = *(__attribute__((address_space(3))) const u64*)(size_t)(r8 << 3);
+    }
+    __device__ __forceinline__ void s3(const dec_quad_const& qc)  // state update, renormalise?, byte cursor -> stream window
+    {
+        const u32 fr = (u32)t_e & 0xFFFFu, base = (u32)t_e >> 16;
+        t_pv = (u32)(t_e >> 32);
+        const u64 t = (u64)fr * (u32)t_qs + (u64)(t_slot - base);  // ans_fold.hpp:218-220
+        t_nlo = (u32)t;
+        t_nhi = (u32)(t >> 32) + __umul24(fr, (u32)(t_qs >> 32));
+        t_rn = t_nhi == 0 && t_nlo < (u32)Lb;
+        const u32 k = t_pv >> 30;
+        const u32 cq = (k << qc.ql8) + (t_rn ? qc.four_pos : 0u);
+        const u32 s1_ = quad_add_dpp<0xB1>(cq);
+        const u32 S = quad_add_dpp<0x4E>(s1_);
+        const u32 a = 0u - __builtin_amdgcn_sad_u8(S & qc.lomask, 0u, q);
+        q = __builtin_amdgcn_sad_u8(S, 0u, q);
+        typedef __attribute__((address_space(3))) const u32 lds_cu32;
+        const u32 rb = (u32)(size_t)(__attribute__((address_space(3))) const void*)ring;
+        lds_cu32* wp = (lds_cu32*)(size_t)(rb + (a & (ANSX_RING_BYTES - 4)));
+        t_w0 = wp[0], t_w1 = wp[1], t_w2 = wp[2];
+        t_sh = a & 3;
+    }
+    __device__ __forceinline__ u32 s4()  // the renormalisation word / exception bytes, the value
+    {
+        const u32 lo = __builtin_amdgcn_alignbyte(t_w1, t_w0, t_sh);
+        const u32 hi = __builtin_amdgcn_alignbyte(t_w2, t_w1, t_sh);
+        const u32 s_lo = t_rn ? hi : t_nlo, s_hi = t_rn ? t_nlo : t_nhi;  // ans_fold.hpp:221-225
+        st = ((u64)s_hi << 32) | s_lo;
+        const u32 k = t_pv >> 30;
+        const u32 e = (u32)((u64)(t_rn ? lo : hi) >> (32u - 8u * k));
+        return (t_pv & ANSX_PV_MASK) + e;
+    }
+};
+
+template <bool RFOLD>
+__global__ __launch_bounds__(256) void k_decode_rank2(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
+    const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
+    u32 max_ns, u64 cont_bytes, const u32* __restrict__ g_cum, const uint4* __restrict__ binfo,
+    u32* __restrict__ gflags)
+{
+    // (no static LDS in this kernel: the interleaved bitmap table sits at LDS address 0)
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    constexpr int RB = ANSX_RING_BYTES, CHK = ANSX_RING_CHK;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u32 bA = 2 * blockIdx.x, bB = bA + 1;
+    const bool hasB = bB < g.nblocks;
+    const u32 bBs = hasB ? bB : bA;  // (a valid index for the loads of an absent second block)
+    const u32* gcA = g_cum + (u64)bA * (NSP + 8);
+    const u32* gcB = g_cum + (u64)bBs * (NSP + 8);
+    u32 curA[4], prvA[4], curB[4], prvB[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+        const u32 s = q * nt + tid;
+        curA[q] = s < NSP ? gcA[s + 1] : 0u;
+        prvA[q] = (s < NSP && s) ? gcA[s] : 0u;
+        curB[q] = s < NSP ? gcB[s + 1] : 0u;
+        prvB[q] = (s < NSP && s) ? gcB[s] : 0u;
+    }
+    const uint4 biA = binfo[bA], biB = binfo[bBs];
+    const u64 boffA = block_off[bA], boffA1 = block_off[bA + 1], boffB1 = block_off[bBs + 1];
+    const u64 boffB = hasB ? boffA1 : boffA;
+    bool okA = biA.w == 0, okB = hasB && biB.w == 0;  // (a parse error is already flagged)
+    const u32 logMA = biA.y, logMB = biB.y;
+    const u32 nbA = geo_block_n(g, bA), nbB = geo_block_n(g, bBs);
+    const u8* streamA = cont + payload_off + boffA;
+    const u8* streamB = cont + payload_off + boffB;
+    const u32 sbA = (u32)(boffA1 - boffA), sbB = (u32)(boffB1 - boffB);
+    const u32 MA = 1u << logMA, MB = 1u << logMB;
+    // LDS carve: [interleaved bitmap + prefix entries][entries A][entries B][scratch][rings A][rings B]
+    const u32 wmax = maxM >= 32 ? maxM / 32 : 1;
+    u32 off = 0;
+    u32* bw = (u32*)(smem + off);
+    off += wmax * 16;
+    const u32 epb = 2 * ((max_ns * 4 + 15) & ~15u);
+    uint2* epA = (uint2*)(smem + off);
+    off += epb;
+    uint2* epB = (uint2*)(smem + off);
+    off += epb;
+    u64* sh_scan = (u64*)(smem + off);
+    u32& sh_bad = *(u32*)(smem + off + 80);
+    off += ANSX_DEC_SCRATCH;
+    u32* lds_rest = (u32*)(smem + off);
+    const u32 labs = (u32)(size_t)(__attribute__((address_space(3))) void*)lds_rest;
+    u32* ringsA = lds_rest + ((((labs + 15u) & ~15u) - labs) >> 2);
+    u32* ringsB = ringsA + (nt >> 2) * (ANSX_RING_STRIDE / 4);
+    const u32 WA = MA >= 32 ? MA / 32 : 1, WB = MB >= 32 ? MB / 32 : 1;
+    // full blocks decode through rings (all segments have g.ckpt ints, host-checked); the container's one partial block
+    // reads its stream straight from HBM
+    const bool ringA = nbA == g.block_ints, ringB = hasB && nbB == g.block_ints;
+    auto make_desc = [&](u64 boff_, u32 sbytes_) {
+        dec_ring_desc D;
+        const u64 sabs = payload_off + boff_;
+        D.backoff = (int)(sabs < 1024 ? sabs : 1024);
+        const u8* base = cont + (sabs - (u64)D.backoff);
+        u64 span = (u64)D.backoff + sbytes_ + 64;
+        const u64 room = cont_bytes - (sabs - (u64)D.backoff);
+        if (span > room) span = room;
+        const u64 ba = (u64)(uintptr_t)base;
+        D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
+        return D;
+    };
+    dec_ring_desc DA = make_desc(boffA, sbA), DB = make_desc(boffB, sbB);
+    dec_ring_pre RPA, RPB;
+#pragma unroll
+    for (int j = 0; j < RB / 64; j++) RPA.r[j] = RPB.r[j] = ansx_u32x4{ 0u, 0u, 0u, 0u };
+    RPA.st = RPB.st = 0;
+    RPA.p = RPB.p = RPA.lo = RPB.lo = 0;
+    if (okA && ringA) dec_ring_prefetch(RPA, g, bA, sbA, tid, logMA, streamA, DA, ckpt_state, ckpt_off);
+    if (okB && ringB) dec_ring_prefetch(RPB, g, bB, sbB, tid, logMB, streamB, DB, ckpt_state, ckpt_off);
+    {
+        const u32 Wz = (WA > WB ? WA : WB) * 4;
+        for (u32 w = tid; w < Wz; w += nt) bw[w] = 0u;
+    }
+    if (tid == 0) {
+        sh_bad = 0;
+        if ((u32)(size_t)(__attribute__((address_space(3))) void*)bw != 0u) atomicOr(&gflags[ANSX_G_ERR], 1u << 3);
+    }
+    __syncthreads();
+    if (okA)
+        okA = dec_build_rank_tables<RFOLD, 4, 0>(g, bw, epA, sh_scan, &sh_bad, gcA, curA, prvA, biA.x, MA, WA, max_ns, biA.z, streamA, tid, nt, gflags);
+    if (okB) {
+        if (tid == 0) sh_bad = 0;
+        __syncthreads();
+        okB = dec_build_rank_tables<RFOLD, 4, 2>(g, bw, epB, sh_scan, &sh_bad, gcB, curB, prvB, biB.x, MB, WB, max_ns, biB.z, streamB, tid, nt, gflags);
+    }
+    u32* oA = outp + (u64)bA * g.block_ints;
+    u32* oB = outp + (u64)bBs * g.block_ints;
+    dec_lut_rank2<0> lutA;
+    dec_lut_rank2<8> lutB;
+    if (okA && ringA && okB && ringB) {
+        const u32 nseg = g.block_ints / g.ckpt;
+        const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
+        const dec_quad_const qc = dec_make_qc(ql);
+        const u32 steps = g.ckpt >> 2;
+        dec_ring_chain<dec_lut_rank2<0>> A;
+        dec_ring_chain<dec_lut_rank2<8>> B;
+        A.setup(ringsA, quad, ql, logMA, DA);
+        B.setup(ringsB, quad, ql, logMB, DB);
+        for (u32 seg = quad; seg < nseg; seg += nq) {
+            ansx_u32x4 ra[RB / 64], rb[RB / 64];
+            if (seg == quad) {
+                A.begin(RPA, ra);
+                B.begin(RPB, rb);
+            } else {
+                A.begin(g, bA, seg, ql, sbA, ckpt_state, ckpt_off, ra);
+                B.begin(g, bB, seg, ql, sbB, ckpt_state, ckpt_off, rb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            A.fill(ra, ql);
+            B.fill(rb, ql);
+            A.op = oA + seg * g.ckpt + ql;
+            B.op = oB + seg * g.ckpt + ql;
+            u32 i = 0;
+            for (; i + CHK <= steps; i += CHK) {
+                // the two requests of the previous interval are older than its 2 CHK output stores
+                if constexpr (CHK == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                A.keep();
+                B.keep();
+                A.land();
+                B.land();
+                A.request();
+                B.request();
+#pragma unroll
+                for (u32 u = 0; u < (u32)CHK; u++) {
+                    // stage by stage, the two chains in turn (the scheduling barriers keep hipcc from putting each chain's
+                    // step back together: left alone it emits A's whole step, then B's, with a full LDS wait between)
+                    A.s1();
+                    B.s1();
+                    __builtin_amdgcn_sched_barrier(0);
+                    A.s2();
+                    B.s2();
+                    __builtin_amdgcn_sched_barrier(0);
+                    A.s3(qc);
+                    B.s3(qc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32 va = A.s4();
+                    const u32 vb = B.s4();
+                    A.op[4 * (i + u)] = va;
+                    B.op[4 * (i + u)] = vb;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            A.keep();
+            B.keep();
+            A.land();
+            B.land();
+            for (; i < steps; i++) {
+                const u32 va = A.step(qc);
+                const u32 vb = B.step(qc);
+                A.op[4 * i] = va;
+                B.op[4 * i] = vb;
+            }
+        }
+        return;
+    }
+    // anything else (the last workgroup of the grid: an odd block count, a partial last block; or a block that failed
+    // its checks): whatever can be decoded is decoded one block at a time
+    if (okA) {
+        if (ringA) dec_segments_ring(g, bA, sbA, tid, nt, logMA, lutA, streamA, ringsA, DA, ckpt_state, ckpt_off, oA, RPA);
+        else dec_segments<false>(g, bA, nbA, sbA, tid, nt, logMA, lutA, streamA, (const u32*)nullptr, ckpt_state, ckpt_off, oA);
+    }
+    if (okB) {
+        if (ringB) dec_segments_ring(g, bB, sbB, tid, nt, logMB, lutB, streamB, ringsB, DB, ckpt_state, ckpt_off, oB, RPB);
+        else dec_segments<false>(g, bB, nbB, sbB, tid, nt, logMB, lutB, streamB, (const u32*)nullptr, ckpt_state, ckpt_off, oB);
+    }
+    // nothing requested by dec_ring_prefetch may still be on its way into a register when the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < RB / 64; j++) asm volatile("" : "+v"(RPA.r[j]), "+v"(RPB.r[j]));
 }
 
 // k_decode: slot -> symbol table form, any frame size; tables in LDS (LDS_TAB) or in HBM.

@@ -210,7 +210,8 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             2^16 turned up in a call laid out for packed restart points and the call was
  *                             repeated with wide ones (remembered per geometry, but only as the attempt to run
  *                             FIRST); + 64: the remembered wide form was not needed by this input and the call was
- *                             repeated with packed restart points.  Either way the output bytes -- the restart-point
+ *                             repeated with packed restart points; + 128: the producer / consumer encoder kernel
+ *                             (k_encode_pc) ran for the call's workgroups of 64 full blocks.  Either way the output bytes -- the restart-point
  *                             format included -- are a function of the input and the options only. */
 typedef struct {
     uint32_t max_nsyms;

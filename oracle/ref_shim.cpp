@@ -33,6 +33,8 @@
 #include "ans_msb.hpp"
 #include "ans_int.hpp"
 #include "zipf_dist.hpp"
+#include "qsufsort.hpp"  // Larsson-Sadakane suffix sort, unmodified (src/generate_bwtmtf.cpp:34)
+#include <deque>
 
 namespace {
 
@@ -258,6 +260,35 @@ int ref_blocks_mt(int kind, int f, const uint32_t* in, size_t n, size_t block_in
     for (const auto& s : streams) tot += s.size();
     *total_bytes = tot;
     return bad.load();
+}
+
+// src/generate_bwtmtf.cpp:142-173 around the UNMODIFIED include/qsufsort.hpp: suffix array of the parsed text T (n1 ints,
+// the last one the 0 terminator word_parse / byte_parse append), BWT, move-to-front ranks.  That TU needs Boost (its
+// option parser and boost::split) and cannot be built here, so its statements are re-typed, as ref_pa_encode does for
+// pseudo_adaptive.cpp; the suffix sort is the reference's own.  Writes min(n1 - 1, n) ranks, returns how many.
+size_t ref_bwtmtf(const int32_t* T_in, size_t n1, size_t n, uint32_t* mtf_out)
+{
+    std::vector<int> T(T_in, T_in + n1);
+    std::vector<int> text = T;
+    std::vector<int> SA(T.size());
+    const auto [min, max] = std::minmax_element(T.begin(), T.end() - 1);
+    const int max_sym = *max;                                              // (suffixsort overwrites T)
+    suffixsort(T.data(), SA.data(), T.size() - 1, *max + 1, *min);         // :148
+    std::vector<int> BWT(T.size());
+    for (size_t i = 0; i < text.size(); i++)                               // :152-156
+        BWT[i] = SA[i] != 0 ? text[SA[i] - 1] : text.back();
+    size_t seq_len = text.size() - 1;                                      // :158-160
+    if (seq_len > n) seq_len = n;
+    std::deque<int> alphabet;                                              // :163-171, get_mtf_rank :111-118
+    for (size_t i = 0; i <= (size_t)max_sym; i++) alphabet.push_back(i);
+    for (size_t i = 0; i < seq_len; i++) {
+        auto sym = BWT[i];
+        auto itr = std::find(std::begin(alphabet), std::end(alphabet), sym);
+        mtf_out[i] = (uint32_t)std::distance(std::begin(alphabet), itr);
+        alphabet.erase(itr);
+        alphabet.push_front(sym);
+    }
+    return seq_len;
 }
 
 } // extern "C"

@@ -110,6 +110,9 @@ def _load_ref(name="libans_ref.so"):
     if hasattr(lib, "ref_pa_encode"):
         lib.ref_pa_encode.restype = C.c_size_t
         lib.ref_pa_encode.argtypes = [C.c_int, C.c_int, _u32p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    if hasattr(lib, "ref_bwtmtf"):
+        lib.ref_bwtmtf.restype = C.c_size_t
+        lib.ref_bwtmtf.argtypes = [np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), C.c_size_t, C.c_size_t, _u32p]
     for fn in ("ref_fold_mapping", "ref_fold_undo_mapping", "ref_fold_exception_bytes"):
         getattr(lib, fn).restype = C.c_uint32
         getattr(lib, fn).argtypes = [C.c_int, C.c_uint32]
@@ -138,6 +141,16 @@ def have_ref():
 
 
 # ---------------------------------------------------------------- convenience wrappers
+
+def ref_bwtmtf(T, n):
+    """src/generate_bwtmtf.cpp:142-173 on the parsed text T (ints, terminated by 0) through oracle/_ref: the reference's
+    own suffix sort (include/qsufsort.hpp, unmodified), its BWT and move-to-front statements.  Returns min(len(T) - 1, n)
+    ranks."""
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    out = np.zeros(max(1, min(T.size - 1, n)), dtype=np.uint32)
+    m = ref().ref_bwtmtf(T, T.size, n, out)
+    return out[:m].copy()
+
 
 def oracle_encode(kind, f, data, ckpt_interval=0):
     """Returns (stream bytes as np.uint8, OracleInfo, ckpt_states[nck,4] u64, ckpt_off[nck] u32)."""

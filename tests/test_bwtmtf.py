@@ -76,6 +76,49 @@ def test_tool_matches_naive_pipeline(tmp_path, words):
     assert np.array_equal(txt, got)
 
 
+def _run_tool_on(T, mode, n, tmp_path, tag):
+    """Rebuild a text whose parse is T (words "w<id>" separated by blanks / the bytes themselves), run the tool."""
+    src = tmp_path / ("in_%s.txt" % tag)
+    if mode == "word":
+        src.write_bytes(b" ".join(b"w%d" % t for t in T))
+    else:
+        src.write_bytes(bytes(T))
+    args = [_tool(), "-i", str(src), "-n", str(n), "-o", str(tmp_path / ("out_%s" % tag))] + (["-w"] if mode == "word" else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    suffix = "-WORD" if mode == "word" else "-CHAR"
+    text = np.fromfile(tmp_path / ("out_%s%s.u32" % (tag, suffix)), dtype=np.uint32)
+    mtf = np.fromfile(tmp_path / ("out_%s%s-BWTMTF.u32" % (tag, suffix)), dtype=np.uint32)
+    return text, mtf
+
+
+def test_tool_matches_reference_pipeline_fixture(tmp_path):
+    """tests/golden/bwtmtf_pipeline.json (made by make_bwtmtf_pipeline_golden.py from oracle/_ref's ref_bwtmtf: the
+    statements of src/generate_bwtmtf.cpp:142-173 around the UNMODIFIED include/qsufsort.hpp): the tool's own suffix
+    sorter and Fenwick-tree move-to-front must give the reference's ranks on every case; where oracle/_ref is present
+    the same comparison runs live on fresh random texts too."""
+    doc = json.load(open(os.path.join(GOLD, "bwtmtf_pipeline.json")))
+    assert len(doc["cases"]) >= 7
+    for i, c in enumerate(doc["cases"]):
+        text, mtf = _run_tool_on(c["T"], c["mode"], c["n"], tmp_path, "g%d" % i)
+        assert np.array_equal(text, np.array(c["T"][:c["n"]], dtype=np.uint32)), c["name"]
+        assert np.array_equal(mtf, np.array(c["mtf"], dtype=np.uint32)), c["name"]
+    if ol.have_ref() and hasattr(ol.ref(), "ref_bwtmtf"):
+        rng = np.random.default_rng(99)
+        for j in range(6):
+            mode = "word" if j % 2 == 0 else "byte"
+            m = int(rng.integers(50, 3000))
+            if mode == "word":
+                raw = np.minimum(rng.zipf(1.2 + 0.2 * j, size=m), 500).tolist()
+                ids, T = {}, []
+                for x in raw:
+                    ids.setdefault(x, len(ids) + 1)
+                    T.append(ids[x])
+            else:
+                T = rng.integers(1, 1 + int(rng.integers(2, 200)), size=m).tolist()
+            text, mtf = _run_tool_on(T, mode, m, tmp_path, "l%d" % j)
+            assert np.array_equal(mtf, ol.ref_bwtmtf(T + [0], m)), (mode, m)
+
+
 def test_bwtmtf_fixture_against_reference_streams(oracle_built):
     """tests/golden/bwtmtf.u32 (+ .json made from oracle/_ref by make_bwtmtf_golden.py): the oracle
     reproduces the reference's bytes on real-text BWT-MTF ranks, whole list and per 16 Ki block."""

@@ -1012,24 +1012,17 @@ __global__ __launch_bounds__(256) void k_build_interp_geo(u32 max_ns, uint2* __r
 
 // W: the arithmetic type -- u64 in general; u32 where the universe is below 2^31 (frames up to 2^30: every quantity
 // below is at most 2 u), half the instructions on a machine without 64-bit integer VALU operations.
+// the arithmetic of one item once its node (a, n, rank) and the three inc[] values around it are known:
+// inc_lo = inc[a - 1] (unused when a == 0), inc_hi = inc[a + n] (unused when a + n == ns), inc_mid = inc[i]
 template <typename W = u64>
-__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, W u, u32 i,
-    const uint2* __restrict__ geo_row = nullptr)
+__device__ __forceinline__ ansx_code interp_code(u32 ns, W u, u32 a, u32 n, u32 rank, u32 inc_lo, u32 inc_hi, u32 inc_mid)
 {
-    u32 a, n, rank;
-    if (geo_row != nullptr) {
-        const uint2 e = geo_row[i];
-        a = e.x & 0xFFFFu, n = e.x >> 16, rank = e.y;
-    } else {
-        const ansx_node nd = interp_node(ns, i);
-        a = nd.a, n = nd.n, rank = nd.rank;
-    }
-    const u32 h = (n + 1) >> 1, mid = i;
+    const u32 h = (n + 1) >> 1;
     const W one = 1;
     const W n1 = h - 1, n2 = n - h;
-    const W low = (a == 0) ? one : (W)inc[a - 1] + 2;          // parent v + 1
-    const W high = (a + n == ns) ? (u + one) : (W)inc[a + n];  // parent v - 1
-    const W v = (W)inc[mid] + one;                             // interp.hpp:73
+    const W low = (a == 0) ? one : (W)inc_lo + 2;            // parent v + 1
+    const W high = (a + n == ns) ? (u + one) : (W)inc_hi;    // parent v - 1
+    const W v = (W)inc_mid + one;                            // interp.hpp:73
     W val = v - low - n1 + one;
     const W U = high - n2 - low - n1 + one;
     ansx_code c;
@@ -1055,6 +1048,51 @@ __device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u3
         c.len = bb;
     }
     return c;
+}
+__device__ __forceinline__ ansx_node interp_node_of(u32 ns, u32 i, const uint2* __restrict__ geo_row)
+{
+    if (geo_row != nullptr) {
+        const uint2 e = geo_row[i];
+        return ansx_node{ e.x & 0xFFFFu, e.x >> 16, e.y };
+    }
+    return interp_node(ns, i);
+}
+// W: the arithmetic type -- u64 in general; u32 where the universe is below 2^31 (frames up to 2^30: every quantity
+// below is at most 2 u), half the instructions on a machine without 64-bit integer VALU operations.
+template <typename W = u64>
+__device__ __forceinline__ ansx_code interp_item(const u32* __restrict__ inc, u32 ns, W u, u32 i,
+    const uint2* __restrict__ geo_row = nullptr)
+{
+    const ansx_node nd = interp_node_of(ns, i, geo_row);
+    const u32 inc_lo = nd.a == 0 ? 0u : inc[nd.a - 1];
+    const u32 inc_hi = nd.a + nd.n == ns ? 0u : inc[nd.a + nd.n];
+    return interp_code<W>(ns, u, nd.a, nd.n, nd.rank, inc_lo, inc_hi, inc[i]);
+}
+// Eight items i0, i0 + 256, ... at once (items at or beyond ns: length 0): all nodes first, then all 24 inc[] reads in
+// flight together, then the arithmetic -- for callers whose inc[] is in HBM, where an item's reads are a round trip
+template <typename W = u64>
+__device__ __forceinline__ void interp_items8(const u32* __restrict__ inc, u32 ns, W u, u32 i0, const uint2* __restrict__ geo_row,
+    ansx_code (&c8)[8])
+{
+    ansx_node nd[8];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 i = i0 + 256 * j;
+        nd[j] = interp_node_of(ns, i < ns ? i : i0, geo_row);
+    }
+    u32 lo[8], hi[8], mid[8];
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 i = i0 + 256 * j;
+        lo[j] = inc[nd[j].a == 0 ? 0u : nd[j].a - 1];                       // (always a valid address; unused where a == 0)
+        hi[j] = inc[nd[j].a + nd[j].n >= ns ? ns - 1 : nd[j].a + nd[j].n];  // (likewise at the right edge)
+        mid[j] = inc[i < ns ? i : i0];
+    }
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        c8[j] = interp_code<W>(ns, u, nd[j].a, nd[j].n, nd[j].rank, lo[j], hi[j], mid[j]);
+        if (i0 + 256 * j >= ns) c8[j].len = 0;
+    }
 }
 
 // Interpolative prelude of one block from inc[] in LDS (workgroup of 256 threads, every thread calls
@@ -1088,9 +1126,14 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
             }
         }
     } else {
-        for (u32 i = tid; i < ns; i += 256) {
-            ansx_code c = interp_item<W>(inc, ns, u, i, geo_row);
-            off[c.rank] = c.len;
+        // (eight items per round: inc[] may live in HBM on this path -- k_model_finish<0> --, where an item's three loads
+        // are a dependent round trip; one item at a time that was 116 of the kernel's 136 us per block on 8000-symbol alphabets)
+        for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
+            ansx_code c8[8];
+            interp_items8<W>(inc, ns, u, i0, geo_row, c8);
+#pragma unroll
+            for (u32 j = 0; j < 8; j++)
+                if (i0 + 256 * j < ns) off[c8[j].rank] = c8[j].len;
         }
         __threadfence_block();  // (off[] and the bit buffer may live in HBM on this path)
     }
@@ -1150,7 +1193,12 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
-        for (u32 i = tid; i < ns; i += 256) place(interp_item<W>(inc, ns, u, i, geo_row));
+        for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
+            ansx_code c8[8];
+            interp_items8<W>(inc, ns, u, i0, geo_row, c8);
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) place(c8[j]);
+        }
         __threadfence_block();
     }
     __syncthreads();
@@ -1537,7 +1585,13 @@ template <> struct enc_tab<true> {
         const u32 k = map_nbytes(mp, x);
         const u32 sym = map_sym(mp, x, k);
         const bool is_hot = sym < nhot;
-        l = hot[is_hot ? sym : sent];
+        // hot rows are u16 RUNNING SUMS (round 4: twice the symbols in the same LDS -- 1151 instead of 576 per block, which
+        // halves the lanes that go to L2 on 2300-symbol alphabets): freq = next - current, base = current; the sentinel
+        // pair {0, 0} gives the word 0
+        typedef __attribute__((address_space(3))) const u16 lds_cu16;
+        lds_cu16* cp = (lds_cu16*)hot + (is_hot ? sym : sent);
+        const u32 c0 = cp[0], c1 = cp[1];
+        l = ((c1 - c0) & 0xFFFFu) | (c0 << 16);
         const u32 voff = is_hot ? ANSX_BUF_OOB : rowoff + 4 * sym;
         u32 e;
         asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(e) : "v"(voff), "s"(trs) : "memory");
@@ -1602,7 +1656,7 @@ template <int CTRL> __device__ __forceinline__ u32 quad_add_dpp(u32 v)
     return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
-#define ANSX_ENC_HOT 577  // MODE 2: LDS row = 576 hot entries + sentinel (odd stride; 16 rows = 36.9 KB per wave)
+#define ANSX_ENC_HOT 577  // MODE 2: words per LDS row = 1152 u16 running sums (1151 hot symbols) + a zero sentinel pair (odd stride; 16 rows = 36.9 KB per wave)
 #define ANSX_ENC_U 8    // table entries per lane fetched ahead
 #define ANSX_ENC_XB 32  // inputs per lane fetched ahead (one super-batch)
 
@@ -1645,7 +1699,35 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
         // flight before the first LDS write (row by row behind a dependent load of the alphabet size this took
         // 90 k cycles, 6 % of the kernel).
         const u32 b0 = wb0;
-        const u32 take = MODE == 2 ? lds_stride - 1 : lds_stride;
+        if constexpr (MODE == 2) {
+            // rows of 2 * lds_stride u16: running sums cum[0 .. H] of the first H = 2 * lds_stride - 3 symbols (cum[0] = 0,
+            // cum[s + 1] = base(s) + freq(s) mod 2^16: the compact entries hold a valid base for absent symbols too), then the
+            // sentinel pair cum[H + 1] = cum[H + 2] = 0.  One row per round, all its loads in flight together.
+            typedef __attribute__((address_space(3))) u16 lds_u16;
+            const u32 H = 2 * lds_stride - 3;
+            const u32 limh = H < NSP ? H : NSP;
+            for (u32 j = 0; j < 16; j++) {
+                if (b0 + j >= g.nblocks) break;
+                const u32* r0 = tab32 + (u64)(b0 + j) * NSP;
+                lds_u16* cum = (lds_u16*)(wtab + j * lds_stride);
+                for (u32 e0 = 0; e0 < limh; e0 += 64 * 10) {
+                    u32 v0[10];
+#pragma unroll
+                    for (int i = 0; i < 10; i++) {
+                        const u32 e = e0 + lane + 64 * i;
+                        v0[i] = e < limh ? r0[e] : 0u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 10; i++) {
+                        const u32 e = e0 + lane + 64 * i;
+                        if (e < H) cum[e + 1] = (u16)(e < limh ? (v0[i] >> 16) + (v0[i] & 0xFFFFu) : 0u);
+                    }
+                }
+                if (lane == 0) cum[0] = 0;
+                if (lane < 2) cum[H + 1 + lane] = 0;
+            }
+        } else {
+        const u32 take = lds_stride;
         const u32 lim = take < NSP ? take : NSP;
         for (u32 j = 0; j < 16; j += 2) {
             if (b0 + j >= g.nblocks) break;
@@ -1667,10 +1749,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
                     if (two) wtab[(j + 1) * lds_stride + e] = v1[i];
                 }
             }
-            if (MODE == 2 && lane == 0) {
-                wtab[j * lds_stride + take] = 0;
-                if (two) wtab[(j + 1) * lds_stride + take] = 0;
-            }
+        }
         }
         __syncthreads();
     }
@@ -1688,8 +1767,9 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
         tab.t = tab32 + (u64)b * NSP;
         tab.hot = wtab + (lane >> 2) * lds_stride;
         const u32 own = B->max_sym + 1;
-        tab.nhot = own < lds_stride - 1 ? own : lds_stride - 1;  // entries of THIS block that were staged
-        tab.sent = lds_stride - 1;
+        const u32 H = 2 * lds_stride - 3;
+        tab.nhot = own < H ? own : H;  // symbols of THIS block whose running sums were staged
+        tab.sent = H + 1;              // u16 index of the zero sentinel pair
         tab.rowoff = (lane >> 2) * NSP * 4;
         const u64 ba = (u64)(uintptr_t)(tab32 + (u64)wb0 * NSP);
         tab.trs = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, 16u * NSP * 4u, 0x00020000u };

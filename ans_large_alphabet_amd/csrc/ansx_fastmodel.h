@@ -559,7 +559,8 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     __syncthreads();  // frq (= bits) has been read by everyone; inc[] is complete
     STAMP(9);
 #ifndef FIN_NO_PRELUDE
-    prelude_emit<IPT, false, true>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (logM <= 16)
+    // (IPT == 0 serves alphabets up to 16384 slots here: 64 items per thread at most, their codes kept in registers)
+    prelude_emit<IPT, false, true, IPT == 0 ? 8 : 0>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (logM <= 16)
 #endif
     STAMP(10);
 }

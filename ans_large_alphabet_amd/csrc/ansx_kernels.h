@@ -1105,7 +1105,10 @@ __device__ __forceinline__ void interp_items8(const u32* __restrict__ inc, u32 n
 // PA == true:  the alphabet header of per-block compaction (pseudo_adaptive.cpp:106-113): u32 ns, u32 `uni`,
 //               code of the ns running sums over universe `uni`; sets B->pre_bytes.
 // W32: the caller guarantees a universe below 2^31 (32-bit code arithmetic, see interp_item).
-template <int IPT, bool PA = false, bool W32 = false>
+// KEEP8 (IPT == 0 only): the caller guarantees ns <= 2048 * KEEP8; the codes of a thread's <= 8 KEEP8 items stay in
+// registers between the two passes (two words each) instead of being derived again -- on alphabets beyond the tabulated
+// tree geometry (> 4096 slots) a derivation is a 14-level descent per item, half of the writer's time there.
+template <int IPT, bool PA = false, bool W32 = false, int KEEP8 = 0>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
     u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
     u64 uni = 0, u32* __restrict__ hints = nullptr, const uint2* __restrict__ geo = nullptr)
@@ -1115,6 +1118,8 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
     typedef typename std::conditional<W32, u32, u64>::type W;
     const W u = (W)(PA ? uni : ((u64)1 << logM) + ns + 1);  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
+    u32 kept_code[KEEP8 > 0 ? 8 * KEEP8 : 1], kept_lr[KEEP8 > 0 ? 8 * KEEP8 : 1];
+    (void)kept_code, (void)kept_lr;
     if (SMALL) {
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) {
@@ -1128,6 +1133,24 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
     } else {
         // (eight items per round: inc[] may live in HBM on this path -- k_model_finish<0> --, where an item's three loads
         // are a dependent round trip; one item at a time that was 116 of the kernel's 136 us per block on 8000-symbol alphabets)
+        if constexpr (KEEP8 > 0) {
+#pragma unroll
+            for (int r = 0; r < KEEP8; r++) {
+                const u32 i0 = tid + 2048u * (u32)r;
+#pragma unroll
+                for (u32 j = 0; j < 8; j++) kept_code[8 * r + j] = 0, kept_lr[8 * r + j] = 0;
+                if (i0 < ns) {
+                    ansx_code c8[8];
+                    interp_items8<W>(inc, ns, u, i0, geo_row, c8);
+#pragma unroll
+                    for (u32 j = 0; j < 8; j++) {
+                        if (i0 + 256 * j < ns) off[c8[j].rank] = c8[j].len;
+                        kept_code[8 * r + j] = c8[j].code;
+                        kept_lr[8 * r + j] = c8[j].len | (c8[j].rank << 8);  // (len 0 beyond ns)
+                    }
+                }
+            }
+        } else
         for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
             ansx_code c8[8];
             interp_items8<W>(inc, ns, u, i0, geo_row, c8);
@@ -1193,6 +1216,14 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) place(mine[j]);
     } else {
+        if constexpr (KEEP8 > 0) {
+#pragma unroll
+            for (int q = 0; q < 8 * KEEP8; q++) {
+                ansx_code c;
+                c.code = kept_code[q], c.len = kept_lr[q] & 0xFFu, c.rank = kept_lr[q] >> 8;
+                place(c);
+            }
+        } else
         for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
             ansx_code c8[8];
             interp_items8<W>(inc, ns, u, i0, geo_row, c8);

@@ -95,6 +95,10 @@ struct ansx_ctx {
         bool use_pc = false;          // ANSX_USE_PC: k_encode_pc (producer / consumer wave pairs) for calls whose grid fills the chip.  Off by default:
                                       // measured EQUAL to k_encode<1> on the headline workload (0.708 vs 0.707 ms) -- the pair's 53 vector
                                       // instructions per symbol fill the SIMD as the lone wave's 44 do
+        u32 pc_b_pairs = 2;           // ANSX_PC_B_PAIRS: pairs per workgroup of shape B (2: one workgroup per CU -- 1.04 ms on BASELINE config 3;
+                                      // 1: two workgroups per CU, whose waves the dispatcher does not spread as evenly -- 1.21 ms)
+        bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (forms B and C of launch_f64_encoder)
+        bool encode_mode2 = false;    // ANSX_ENCODE_MODE2: the compact-table encoder (k_encode<2>) even where the tables fit LDS (tests)
         bool force_pc = false;        // ANSX_FORCE_PC: the pair kernel for every workgroup of 64 full blocks, however few (tests)
         bool no_pc = false;           // ANSX_NO_PC: the LDS-table encoder as one wave per 16 blocks everywhere (k_encode<1>), no producer / consumer pairs
         int decode_pair = 0;          // ANSX_DECODE_PAIR: "0"/unset auto, "never", "always" (k_decode_rank2: two blocks per workgroup)
@@ -375,60 +379,87 @@ int rfold_remap(ansx_ctx* c, const ansx_geo& g, const u32* d_in, u32* mapped, u3
 constexpr int ANSX_RETRY_GENERAL = -1;  // internal: an optimistic assumption did not hold, repeat without it
 constexpr int ANSX_RETRY_WIDE = -2;     // internal: a frame above 2^16 in a call laid out for packed restart points, repeat with wide ones
 
-// K5, LDS-table form (frames <= 2^16, every block's alphabet <= ns_entries): the producer / consumer kernel k_encode_pc over the
-// leading workgroups of 64 full blocks, k_encode<1> over whatever is left (fewer than 64 blocks, the partial last block) or over
-// everything when the geometry rules the pair kernel out.  Returns false if the alphabet does not fit LDS at all (caller: MODE 2).
-static int launch_lds_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32* src, u32 ns_entries, ansx_blk* blk, u64 scr_stride,
-    u64* ck_state, u32* ck_off, u32* enc_sizes, unsigned long long* enc_gsums, u32 NB, hipStream_t s, bool* launched)
+// K5, f64-state forms (frames <= 2^16, every block's alphabet <= ns_entries).  Three kernels share the call's blocks:
+//   k_encode_pc   producer / consumer wave pairs over the leading workgroups of 16 x pairs FULL blocks, where that form wins:
+//                 (B) alphabets too large for 64 tables per CU whose tables fit at 32 (two pairs, S = 4: every entry in LDS,
+//                 two rounds, each wave alone on its SIMD) -- BASELINE config 3; (C) short lists (one pair per workgroup, at
+//                 most two per CU); (A) on request, the chip-filling form (four pairs)
+//   k_encode<1>   one wave per 16 blocks, 4-byte LDS entries: everything else that fits (BASELINE config 2)
+//   k_encode<2>   compact tables in HBM with the hottest 1151 symbols per block in LDS: alphabets that fit neither
+// The kernels behind k_encode_pc take the blocks it leaves (fewer than a workgroup's worth, the partial last block).
+template <bool POW2, int S>
+static int launch_pc(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32* src, u32 ns_entries, u32 rowwords, u32 pairs, u32 wgs,
+    size_t lds, ansx_blk* blk, u64 scr_stride, u64* ck_state, u32* ck_off, u32* enc_sizes, unsigned long long* enc_gsums, hipStream_t s)
 {
-    *launched = false;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_encode_pc<POW2, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAUNCH(c, "k_encode", (k_encode_pc<POW2, S>), wgs, 128 * pairs, lds, s, src, g, NSP, (const u32*)c->tab32.p, ns_entries, rowwords, blk,
+        (u8*)c->scratch.p, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+    return ANSX_OK;
+}
+static int launch_f64_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32* src, u32 ns_entries, ansx_blk* blk, u64 scr_stride,
+    u64* ck_state, u32* ck_off, u32* enc_sizes, unsigned long long* enc_gsums, u32 NB, hipStream_t s)
+{
     c->used_pc = false;
     const u32 lds_stride = ns_entries | 1u;  // odd stride spreads the 16 tables over the banks
     const size_t enc_lds = (size_t)16 * lds_stride * 4;
-    if (enc_lds > 40 * 1024) return ANSX_OK;
-    *launched = true;
+    const bool mode1 = enc_lds <= 40 * 1024 && !c->dbg.encode_mode2;
     const bool pow2 = map_is_pow2(g.map);
+    int rc;
     u32 first = 0;
     // ---- producer / consumer pairs
     const u32 rowwords = ((ns_entries + 2u) / 2u) | 1u;  // ns_entries + 1 running sums of 16 bits, an odd number of words per row
-    const size_t pc_lds = (size_t)64 * rowwords * 4 + (size_t)4 * 2 * ANSX_PC_S * 1024;
     const u32 full_blocks = (u32)(g.n / g.block_ints);
-    const bool pc_ok = (c->dbg.use_pc || c->dbg.force_pc) && !c->dbg.no_pc && ns_entries <= 64u * ANSX_PC_MAXLD && pc_lds <= 160 * 1024 && g.block_ints % (16u * ANSX_PC_S * 2u) == 0
-        && (g.ckpt == 0 || g.ckpt % (4u * ANSX_PC_S) == 0) && (u64)scr_stride * 16 < 0x40000000ull && full_blocks >= 64
-        && ((full_blocks / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc);  // (a grid that leaves most CUs idle is better served by one wave per workgroup)
-    if (pc_ok) {
-        const u32 wgs = full_blocks / 64;
-        if (pow2) {
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode_pc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
-            LAUNCH(c, "k_encode", (k_encode_pc<true>), wgs, 512, pc_lds, s, src, g, NSP, (const u32*)c->tab32.p, ns_entries, rowwords, blk,
-                (u8*)c->scratch.p, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
-        } else {
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode_pc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
-            LAUNCH(c, "k_encode", (k_encode_pc<false>), wgs, 512, pc_lds, s, src, g, NSP, (const u32*)c->tab32.p, ns_entries, rowwords, blk,
-                (u8*)c->scratch.p, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
-        }
-        first = wgs * 64;
+    const u32 enc_waves_all = (NB + 15) / 16;
+    auto pc_lds = [&](u32 pairs, u32 S) { return (size_t)pairs * 16 * rowwords * 4 + (size_t)pairs * 2 * S * 1024; };
+    u32 pairs = 0, S = 0;
+    const bool pc_geo = !c->dbg.no_pc && g.block_ints % 128u == 0 && (u64)scr_stride * 16 < 0x40000000ull;
+    if (pc_geo && (c->dbg.use_pc || c->dbg.force_pc) && mode1 && pc_lds(4, 8) <= 160 * 1024
+        && ((full_blocks / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc))
+        pairs = 4, S = 8;                                                    // (A) on request
+    else if (pc_geo && !mode1 && pc_lds(2, 4) <= 160 * 1024 && full_blocks >= 32 && !c->dbg.no_pc_auto)
+        pairs = c->dbg.pc_b_pairs, S = 4;                                    // (B) every table entry in LDS, two rounds
+    else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && full_blocks >= 16 && !c->dbg.no_pc_auto)
+        pairs = 1, S = 8;                                                    // (C) short lists
+    if (pairs && (g.ckpt == 0 || g.ckpt % (4u * S) == 0)) {
+        const u32 wgs = full_blocks / (16 * pairs);
+        const size_t lds = pc_lds(pairs, S);
+        if (pow2) rc = S == 8 ? launch_pc<true, 8>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s)
+                              : launch_pc<true, 4>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s);
+        else rc = S == 8 ? launch_pc<false, 8>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s)
+                         : launch_pc<false, 4>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s);
+        if (rc) return rc;
+        first = wgs * 16 * pairs;
         c->used_pc = true;
         if (first >= NB) return ANSX_OK;
     }
-    // ---- one wave per 16 blocks.  Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four waves
-    // per workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
     const u32 enc_waves = (NB - first + 15) / 16;
     u32 wpw = (enc_waves + c->num_cus - 1) / c->num_cus;
     wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);
     const size_t enc_grid = (enc_waves + wpw - 1) / wpw;
-    if (wpw * enc_lds > 48 * 1024) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+    if (mode1) {
+        // ---- one wave per 16 blocks.  Waves of one workgroup run the main loop in step (a barrier per super-batch): up to four
+        // waves per workgroup -- one per SIMD of a CU -- as soon as there are that many waves per CU (see k_encode)
+        if (wpw * enc_lds > 48 * 1024) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wpw * enc_lds)));
+        }
+        if (pow2)
+            LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
+        else
+            LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
+                (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
+                (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
+        return ANSX_OK;
     }
-    if (pow2)
-        LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, true>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
-    else
-        LAUNCH(c, first ? "k_encode_rest" : "k_encode", (k_encode<1, false>), enc_grid, 64 * wpw, wpw * enc_lds, s, src, g, NSP,
-            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, lds_stride, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
+    // ---- alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
+    const size_t lds2 = (size_t)wpw * 16 * ANSX_ENC_HOT * 4;
+    if (lds2 > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    LAUNCH(c, first ? "k_encode_rest" : "k_encode_gtab", (k_encode<2>), enc_grid, 64 * wpw, lds2, s, src, g, NSP,
+        (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
+        (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, first);
     return ANSX_OK;
 }
 
@@ -740,22 +771,8 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // (its emitted-byte stores go through a buffer descriptor spanning the wave's 16 scratch slots:
     // 31-bit offsets)
     const bool f64_ok = max_logM <= 16 && (u64)scr_stride * 16 < 0x7FFFFF00ull && !test_fixup;
-    bool lds_launched = false;
-    if (f64_ok) {
-        if ((rc = launch_lds_encoder(c, g, NSP, src, max_ns, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s, &lds_launched))) return rc;
-    }
-    if (lds_launched) {
-    } else if (f64_ok && !c->dbg.encode_gtab16) {
-        // alphabets too large for LDS: compact table entries from HBM, same branch-free f64 step
-        const u32 w2 = (NB + 15) / 16;
-        u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
-        wpw2 = wpw2 < 1 ? 1 : (wpw2 > 4 ? 4 : wpw2);
-        const size_t lds2 = (size_t)wpw2 * 16 * ANSX_ENC_HOT * 4;
-        if (lds2 > 48 * 1024)
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
-            (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+    if (f64_ok && !c->dbg.encode_gtab16) {
+        if ((rc = launch_f64_encoder(c, g, NSP, src, max_ns, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s))) return rc;
     } else {
         LAUNCH(c, "k_encode_gtab", (k_encode<0>), ((size_t)NB * 4 + 63) / 64, 64, 0, s, src, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, 0u, blk, (u8*)c->scratch.p,
@@ -893,22 +910,9 @@ int encode_fast(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_t c
     }
     u64* ck_state = (u64*)(d_out + P.lay.ckstate_off);
     u32* ck_off = (u32*)(d_out + P.lay.ckoff_off);
-    bool lds_launched = false;
     {
         int rcl;
-        if ((rcl = launch_lds_encoder(c, g, NSP, src, ns_cap, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s, &lds_launched))) return rcl;
-    }
-    if (lds_launched) {
-    } else {
-        const u32 w2 = (NB + 15) / 16;
-        u32 wpw2 = (w2 + c->num_cus - 1) / c->num_cus;
-        wpw2 = wpw2 < 1 ? 1 : (wpw2 > 4 ? 4 : wpw2);
-        const size_t lds2 = (size_t)wpw2 * 16 * ANSX_ENC_HOT * 4;
-        if (lds2 > 48 * 1024)
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_encode<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        LAUNCH(c, "k_encode_gtab", (k_encode<2>), (w2 + wpw2 - 1) / wpw2, 64 * wpw2, lds2, s, src, g, NSP,
-            (const ansx_enc_entry*)nullptr, (const u32*)c->tab32.p, (u32)ANSX_ENC_HOT, blk, (u8*)c->scratch.p,
-            (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums);
+        if ((rcl = launch_f64_encoder(c, g, NSP, src, ns_cap, blk, (u64)scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, NB, s))) return rcl;
     }
     u64* boff = (u64*)(d_out + P.lay.index_off);
     if (NB <= 65536u) {
@@ -1709,6 +1713,9 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NO_PC")) c->dbg.no_pc = on;
     else if (!strcmp(name, "ANSX_FORCE_PC")) c->dbg.force_pc = on;
     else if (!strcmp(name, "ANSX_USE_PC")) c->dbg.use_pc = on;
+    else if (!strcmp(name, "ANSX_NO_PC_AUTO")) c->dbg.no_pc_auto = on;
+    else if (!strcmp(name, "ANSX_PC_B_PAIRS")) c->dbg.pc_b_pairs = (value && value[0] == '1') ? 1u : 2u;
+    else if (!strcmp(name, "ANSX_ENCODE_MODE2")) c->dbg.encode_mode2 = on;
     else if (!strcmp(name, "ANSX_DECODE_PAIR"))
         c->dbg.decode_pair = !value ? 0 : !strcmp(value, "never") ? 1 : !strcmp(value, "always") ? 2 : 0;
     else if (!strcmp(name, "ANSX_DECODE_PAIR_LDS")) c->dbg.pair_lds_limit = (value && value[0]) ? (u32)strtoul(value, nullptr, 10) : 0u;

@@ -2207,59 +2207,61 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
 // frame size (freq = next - current; two adjacent ds_read_u16 as before): half the LDS of the 4-byte entries, which is
 // what makes room for the hand-over buffers (2 x S x 1 KB per pair).  One workgroup barrier per batch; double-buffered.
 // Host-checked: every block of the workgroup is a full block, block_ints % (4 S * 4) == 0 (no tail, no leading
-// remainder), restart interval a multiple of 4 S; the other blocks of the call go to k_encode<1>.
-#define ANSX_PC_S 8
-#define ANSX_PC_MAXLD 12  // staging: table entries per lane (alphabets up to 64 * 12 symbols)
+// remainder), restart interval a multiple of 4 S; the other blocks of the call go to k_encode<1> / k_encode<2>.
+#define ANSX_PC_S 8  // (steps per batch of the default form; the kernel is a template over it)
 __device__ __forceinline__ void pc_store_short_hi(u32 v, ansx_u32x4 rs, u32 voff)
 {
     asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
 }
-template <bool POW2>
+// Launch shapes (blockDim.x = 128 * pairs; wave w < pairs is the consumer of pair w, wave pairs + w its producer):
+//   4 pairs, S = 8   one workgroup per CU, a producer and a consumer on every SIMD: as fast as k_encode<1>, no faster
+//                    (the pair's 53 vector instructions per symbol fill the SIMD as the lone wave's 44 do) -- opt-in;
+//   2 pairs, S = 4   alphabets of up to ~2400 symbols (BASELINE config 3: 2296) with EVERY table entry in LDS: 32 blocks per
+//                    CU instead of 64, so the call takes two rounds, but every wave has a SIMD to itself and the consumer's
+//                    35 instructions per symbol run at the lone-wave rate -- faster than the compact-table mode (MODE 2 of
+//                    k_encode), whose cold look-ups were 4-byte gathers into a 150 MB working set;
+//   1 pair,  S = 8   short lists (at most two such workgroups per CU): the state chain of a lone wave is what such a call
+//                    waits for, and the consumer's is 20 % shorter.
+template <bool POW2, int S>
 __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, ansx_geo g, u32 NSP,
     const u32* __restrict__ tab32, u32 ns_cap, u32 rowwords, ansx_blk* __restrict__ blk, u8* __restrict__ scratch,
     u64 scr_stride, u64* __restrict__ ckpt_state, u32* __restrict__ ckpt_off, u32* __restrict__ sizes,
     unsigned long long* __restrict__ gsums)
 {
+    static_assert(S == 4 || S == 8, "the input ring is 32 steps deep: 4 or 8 batches per super-batch");
     extern __shared__ u32 lds_pc[];
-    constexpr int S = ANSX_PC_S;
     typedef __attribute__((address_space(3))) u16 lds_u16;
     typedef __attribute__((address_space(3))) ansx_u32x4 lds_x4;
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32 pair = wv & 3u;
-    const bool producer = wv >= 4u;
-    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + pair) * 16));  // first block of this pair (uniform)
+    const u32 pairs = blockDim.x >> 7;
+    const bool producer = wv >= pairs;
+    const u32 pair = producer ? wv - pairs : wv;
+    const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * pairs + pair) * 16));  // first block of this pair (uniform)
     u32* const ptab = lds_pc + pair * 16 * rowwords;  // the pair's 16 rows of running sums (u16), rowwords words each
-    u32* const hand = lds_pc + 64 * rowwords + pair * (2 * S * 64 * 4);
+    u32* const hand = lds_pc + pairs * 16 * rowwords + pair * (2 * S * 64 * 4);
     {
-        // Both waves of a pair stage its tables, eight rows each, two rows per round with every load of a round in flight:
-        // cum[0] = 0, cum[s + 1] = base(s) + freq(s) mod 2^16 (the compact entries hold a valid base for absent symbols too;
-        // what lies beyond a block's own alphabet is never looked up)
+        // Both waves of a pair stage its tables, eight rows each, a row at a time with all loads of a 640-entry piece in
+        // flight: cum[0] = 0, cum[s + 1] = base(s) + freq(s) mod 2^16 (the compact entries hold a valid base for absent symbols
+        // too; what lies beyond a block's own alphabet is never looked up)
         const u32 r0 = producer ? 8u : 0u;
         const u32 lim = ns_cap < NSP ? ns_cap : NSP;
-        for (u32 j = 0; j < 8; j += 2) {
+        for (u32 j = 0; j < 8; j++) {
             const u32* row0 = tab32 + (u64)(wb0 + r0 + j) * NSP;
-            const u32* row1 = row0 + NSP;
-            u32 v0[ANSX_PC_MAXLD], v1[ANSX_PC_MAXLD];
-#pragma unroll
-            for (int i = 0; i < ANSX_PC_MAXLD; i++) {
-                const u32 e = lane + 64 * i;
-                v0[i] = e < lim ? row0[e] : 0u;
-                v1[i] = e < lim ? row1[e] : 0u;
-            }
             lds_u16* c0 = (lds_u16*)(ptab + (r0 + j) * rowwords);
-            lds_u16* c1 = (lds_u16*)(ptab + (r0 + j + 1) * rowwords);
+            for (u32 e0 = 0; e0 < lim; e0 += 640) {
+                u32 v0[10];
 #pragma unroll
-            for (int i = 0; i < ANSX_PC_MAXLD; i++) {
-                const u32 e = lane + 64 * i;
-                if (e < lim) {
-                    c0[e + 1] = (u16)((v0[i] >> 16) + (v0[i] & 0xFFFFu));
-                    c1[e + 1] = (u16)((v1[i] >> 16) + (v1[i] & 0xFFFFu));
+                for (int i = 0; i < 10; i++) {
+                    const u32 e = e0 + lane + 64 * i;
+                    v0[i] = e < lim ? row0[e] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    const u32 e = e0 + lane + 64 * i;
+                    if (e < lim) c0[e + 1] = (u16)((v0[i] >> 16) + (v0[i] & 0xFFFFu));
                 }
             }
-            if (lane == 0) {
-                c0[0] = 0;
-                c1[0] = 0;
-            }
+            if (lane == 0) c0[0] = 0;
         }
     }
     __syncthreads();
@@ -2299,17 +2301,17 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             const u32 vnext = vcur - 16 * ANSX_ENC_XB;
 #pragma unroll
             for (int t = 0; t < ANSX_ENC_XB / S; t++) {
-                // the eight registers the previous batch released take the inputs of their steps in the next super-batch (the
-                // last eight of THIS one when requested at step 0, which they hold already)
+                // the S registers the previous batch released take the inputs of their steps in the next super-batch (the
+                // last S of THIS one when requested at step 0, which they hold already)
 #pragma unroll
                 for (int i = 0; i < S; i++) {
                     const int e = (t * S + ANSX_ENC_XB - S + i) % ANSX_ENC_XB;
                     if (t == 0) ANSX_XLOAD(xa[e], vcur, e);
                     else ANSX_XLOAD(xa[e], vnext, e);
                 }
-                // this batch's registers were requested three requests ago: 3 x S younger loads are in flight
-                asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                static_assert(S == 8, "the wait above counts three requests of eight loads");
+                // this batch's registers were requested 32 / S - 1 requests ago: 32 - S younger loads are in flight
+                if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < S; i++) asm volatile("" : "+v"(xa[t * S + i]));
                 u32 kk[S], shh[S], cur[S], nxt[S];

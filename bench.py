@@ -937,7 +937,8 @@ def main():
             "config": {"workload": "ANS%s-%d on %d uint32 per GPU, %s, blocks of %d ints, restart every %d"
                                    % (args.codec, args.fidelity, n, args.dist, block_ints,
                                       args.ckpt or A.DEFAULT_CKPT_INTERVAL),
-                       "codec": codec.name(), "seed": SEED, "multi_gpu": multi_gpu},
+                       "codec": codec.name(), "ints_per_gpu": n, "distribution": args.dist, "block_ints": block_ints,
+                       "ckpt_interval": args.ckpt or A.DEFAULT_CKPT_INTERVAL, "seed": SEED, "multi_gpu": multi_gpu},
             "roundtrip_ok": ok, "merged_container_ok": merged_ok, "bits_per_int": 8 * c_bytes,
             "near_threshold_decisions": stats["near_threshold_decisions"], "encode_path": stats["path"],
             "roofline": roofline,

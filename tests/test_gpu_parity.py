@@ -950,7 +950,7 @@ def test_encoder_producer_consumer_pairs(A):
         ("const7", ol.FOLD, 1, 1024, 256, 64 * 1024),                            # one symbol, frame 32768
     ]
     for fam, kind, f, block, ck, n in cases:
-        expect_pc = fam != "sparse_large"  # (alphabets of ~1000 symbols do not fit 16 LDS tables per wave: compact-table mode)
+        expect_pc = True  # (alphabets of ~1000 symbols do not fit 64 LDS tables per CU: the two-round shape takes them)
         if fam == "const7":
             data = np.full(n, 7, dtype=np.uint32)
         else:
@@ -968,6 +968,32 @@ def test_encoder_producer_consumer_pairs(A):
         for call in range(3):  # discovery, then hinted (fast model path from the second on)
             got = codec.encode(data)
             assert bool(c_pc.last_encode_stats()["path"] & 128) == expect_pc, (fam, kind, f, block, ck, call)  # the pair kernel really ran
+            assert np.array_equal(got, ref), (fam, kind, f, block, ck, call)
+        check_container(A, got, data, kind, f, block, ck)
+        assert np.array_equal(codec.decode(got, n), data)
+        c_pc.close()
+    # the two shapes the launch site chooses by itself: (C) short lists -- one pair per workgroup -- and (B) alphabets too
+    # large for 64 LDS tables per CU whose tables fit at 32 (two pairs per workgroup, batches of 4 steps; BASELINE config 3)
+    auto = [("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3 + 1024 * 2 + 5),    # C: three workgroups + two blocks + a tail
+            ("uniform256", ol.MSB, 0, 512, 0, 16 * 512),                           # C: one workgroup, no restart points
+            ("zipf24", ol.FOLD, 3, 1024, 256, 32 * 1024 * 2 + 1024 * 3 + 9),        # B: two workgroups + rest through k_encode<2>
+            ("zipf24", ol.RFOLD, 3, 2048, 512, 32 * 2048),                         # B: exactly one workgroup
+            ("uniform24", ol.FOLD, 3, 1024, 16, 32 * 1024 + 1024)]                 # B: a restart point every 4 groups (one batch)
+    for fam, kind, f, block, ck, n in auto:
+        data = ol.gen_inputs(fam, n, seed=77 + f + block)
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        kw = dict(block_ints=block, ckpt_interval=ck if ck else A.NO_CHECKPOINTS)
+        c_ref = A.Context(0)
+        c_ref.debug_set("ANSX_NO_PC", "1")
+        ref = codec_for(A, c_ref, kind, f, **kw).encode(data)
+        assert not (c_ref.last_encode_stats()["path"] & 128)
+        c_ref.close()
+        c_pc = A.Context(0)
+        codec = codec_for(A, c_pc, kind, f, **kw)
+        for call in range(3):
+            got = codec.encode(data)
+            assert c_pc.last_encode_stats()["path"] & 128, (fam, kind, f, block, ck, call)
             assert np.array_equal(got, ref), (fam, kind, f, block, ck, call)
         check_container(A, got, data, kind, f, block, ck)
         assert np.array_equal(codec.decode(got, n), data)

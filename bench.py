@@ -318,14 +318,17 @@ def issue_floor(kernel, workload_hint=None):
     memory-side work.  Returns (ms, source) or (None, reason)."""
     try:
         paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+        docs = []
         for path in reversed(paths):
             with open(path) as fh:
-                doc = json.load(fh)
-            if workload_hint and doc.get("workload") not in (None, workload_hint):
-                continue
+                docs.append((path, json.load(fh)))
+        # the newest summary of THIS workload; summaries older than round 4 carry no workload string and are config 2's
+        ranked = [pd for pd in docs if workload_hint and pd[1].get("workload") == workload_hint] \
+            + [pd for pd in docs if pd[1].get("workload") is None and workload_hint and "zipf20s1.2" in workload_hint and "ANSfold-1," in workload_hint]
+        for path, doc in ranked:
             for name, v in doc.get("kernels", {}).items():
                 base = name.split("<")[0]
-                if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode"):
+                if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel in ("k_encode_gtab", "k_encode") and base in ("k_encode", "k_encode_pc")):
                     # (collect.sh profiles `bench.py --steps 1 --warmup 0`: the discovery step + the timed one = 2 launches of
                     # every per-step kernel; summaries written since round 4 carry the dispatch count themselves)
                     waves = float(v["waves"]) / max(1.0, float(v.get("launches", 2)))

@@ -44,7 +44,13 @@ for k, v in kern.items():
         for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c + "_per_wave" in v:
                 v[c.lower().replace("sq_", "frac_")] = v[c + "_per_wave"] / wc
-doc = {"note": "rocprofv3 --kernel-trace --pmc <SQ set> (three separate passes), python3 bench.py --steps 1 --warmup 0 "
+workload = None
+try:
+    cfg = json.load(open(os.path.join(out, "fetch.json")))["config"]
+    workload = "%s, %d ints, %s, block %d, ckpt %d" % (cfg["codec"], cfg["ints_per_gpu"], cfg["distribution"], cfg["block_ints"], cfg["ckpt_interval"])
+except Exception:  # noqa: BLE001
+    pass
+doc = {"workload": workload, "note": "rocprofv3 --kernel-trace --pmc <SQ set> (three separate passes), python3 bench.py --steps 1 --warmup 0 "
                "--no-cpu --no-profile --no-extra; sums over all launches of a kernel divided by its wave count; cycle "
                "counters multiplied by 4 (SQ counts in units of 4 shader clocks)",
        "kernels": kern}

@@ -923,3 +923,139 @@ void ans_oracle_prelude_hints(const uint8_t* prelude, uint32_t* hints)
     hints_walk(&r, nsyms, 1, (1ull << lg) + nsyms + 1 + 1, 0, 0, hints);
     hints[0] = (uint32_t)r.bitpos;
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole lists, block by block, multi-threaded (test infrastructure for full-size parity).
+ * ------------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+uint64_t ans_oracle_hash(const uint8_t* p, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+    }
+    for (; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+typedef struct {
+    int kind;
+    uint32_t f;
+    const uint32_t* in;
+    size_t n, block_ints, ckpt, nblocks;
+    uint32_t *sizes, max_lg, max_ns;
+    uint64_t *stream_hash, *ckpt_digest;
+    size_t next;
+    int bad;
+    pthread_mutex_t mu;
+    /* hash_spans */
+    const uint8_t* buf;
+    const uint64_t* offs;
+    uint64_t* out;
+} blocks_job;
+
+static void* blocks_worker(void* arg)
+{
+    blocks_job* J = (blocks_job*)arg;
+    const size_t cap = ans_oracle_bound(J->kind, J->f, J->block_ints);
+    const size_t nck_max = J->ckpt ? J->block_ints / J->ckpt + 1 : 1;
+    uint8_t* out = (uint8_t*)malloc(cap);
+    uint64_t* st = (uint64_t*)malloc(nck_max * 4 * sizeof(uint64_t));
+    uint32_t* off = (uint32_t*)malloc(nck_max * sizeof(uint32_t));
+    uint32_t my_lg = 0, my_ns = 0;
+    int bad = (!out || !st || !off);
+    for (;;) {
+        pthread_mutex_lock(&J->mu);
+        const size_t b = J->next;
+        J->next += 16;
+        pthread_mutex_unlock(&J->mu);
+        if (b >= J->nblocks || bad) break;
+        for (size_t bb = b; bb < b + 16 && bb < J->nblocks; bb++) {
+            const size_t lo = bb * J->block_ints, cnt = J->n - lo < J->block_ints ? J->n - lo : J->block_ints;
+            ans_oracle_info info;
+            size_t nck = 0;
+            const size_t nb = ans_oracle_encode(J->kind, J->f, J->in + lo, cnt, out, cap, &info, J->ckpt, st, off, &nck);
+            if (!nb) {
+                bad = 1;
+                break;
+            }
+            J->sizes[bb] = (uint32_t)nb;
+            J->stream_hash[bb] = ans_oracle_hash(out, nb);
+            uint64_t dg = 0;
+            for (size_t s = 0; s < nck; s++) {
+                for (int j = 0; j < 4; j++) dg += st[4 * s + j] * (2654435761ull + 2ull * (4 * s + (size_t)j));
+                dg += (uint64_t)off[s] * (40503ull + 2ull * s);
+            }
+            J->ckpt_digest[bb] = dg;
+            if (info.log2_frame > my_lg) my_lg = info.log2_frame;
+            if (info.max_sym + 1 > my_ns) my_ns = info.max_sym + 1;
+        }
+    }
+    pthread_mutex_lock(&J->mu);
+    if (bad) J->bad = 1;
+    if (my_lg > J->max_lg) J->max_lg = my_lg;
+    if (my_ns > J->max_ns) J->max_ns = my_ns;
+    pthread_mutex_unlock(&J->mu);
+    free(out);
+    free(st);
+    free(off);
+    return NULL;
+}
+
+static void* spans_worker(void* arg)
+{
+    blocks_job* J = (blocks_job*)arg;
+    for (;;) {
+        pthread_mutex_lock(&J->mu);
+        const size_t b = J->next;
+        J->next += 64;
+        pthread_mutex_unlock(&J->mu);
+        if (b >= J->nblocks) break;
+        for (size_t i = b; i < b + 64 && i < J->nblocks; i++)
+            J->out[i] = ans_oracle_hash(J->buf + J->offs[i], (size_t)(J->offs[i + 1] - J->offs[i]));
+    }
+    return NULL;
+}
+
+static void run_threads(blocks_job* J, int threads, void* (*fn)(void*))
+{
+    pthread_t th[64];
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pthread_mutex_init(&J->mu, NULL);
+    int started = 0;
+    for (int t = 0; t < threads; t++)
+        if (pthread_create(&th[started], NULL, fn, J) == 0) started++;
+    if (!started) fn(J);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    pthread_mutex_destroy(&J->mu);
+}
+
+int ans_oracle_blocks_digest(int kind, uint32_t f, const uint32_t* in, size_t n, size_t block_ints, size_t ckpt_interval,
+    int threads, uint32_t* sizes, uint64_t* stream_hash, uint64_t* ckpt_digest, uint32_t* max_log2_frame, uint32_t* max_nsyms)
+{
+    if (!n || !block_ints) return -1;
+    blocks_job J;
+    memset(&J, 0, sizeof(J));
+    J.kind = kind, J.f = f, J.in = in, J.n = n, J.block_ints = block_ints;
+    J.ckpt = ckpt_interval >= block_ints ? 0 : ckpt_interval;
+    J.nblocks = (n + block_ints - 1) / block_ints;
+    J.sizes = sizes, J.stream_hash = stream_hash, J.ckpt_digest = ckpt_digest;
+    run_threads(&J, threads, blocks_worker);
+    if (max_log2_frame) *max_log2_frame = J.max_lg;
+    if (max_nsyms) *max_nsyms = J.max_ns;
+    return J.bad ? -1 : 0;
+}
+
+void ans_oracle_hash_spans(const uint8_t* buf, const uint64_t* offs, size_t nspans, int threads, uint64_t* out)
+{
+    blocks_job J;
+    memset(&J, 0, sizeof(J));
+    J.buf = buf, J.offs = offs, J.out = out, J.nblocks = nspans;
+    run_threads(&J, threads, spans_worker);
+}

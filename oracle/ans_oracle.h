@@ -90,6 +90,19 @@ int ans_oracle_pa_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes,
 /* Parse hints of a codec prelude for this build's container index (8 words, see ans_oracle.c). */
 void ans_oracle_prelude_hints(const uint8_t* prelude, uint32_t* hints);
 
+/* Every block of a list at once, on `threads` host threads (full-size parity: tests compare EVERY block of a 256 Mi-int
+ * container with this, not a sample).  Block b = in[b * block_ints ...) is one ans_oracle_encode call with restart points
+ * every ckpt_interval ints (0 = none).  Per block: sizes[b] = stream bytes, stream_hash[b] = ans_oracle_hash of the stream,
+ * ckpt_digest[b] = sum over restart points s and states j of state * (2654435761 + 2 (4 s + j)) + offset * (40503 + 2 s),
+ * modulo 2^64 (what a test recomputes from a parsed container with numpy), max_log2_frame / max_nsyms = the container
+ * header's fields.  Returns 0, or -1 if a block failed. */
+int ans_oracle_blocks_digest(int kind, uint32_t f, const uint32_t* in, size_t n, size_t block_ints, size_t ckpt_interval,
+    int threads, uint32_t* sizes, uint64_t* stream_hash, uint64_t* ckpt_digest, uint32_t* max_log2_frame, uint32_t* max_nsyms);
+/* FNV-1a (64 bit) over 8-byte little-endian words of the span, the tail bytes one by one */
+uint64_t ans_oracle_hash(const uint8_t* p, size_t n);
+/* the same over nspans spans [offs[i], offs[i + 1]) of buf, on `threads` host threads */
+void ans_oracle_hash_spans(const uint8_t* buf, const uint64_t* offs, size_t nspans, int threads, uint64_t* out);
+
 /* Worst-case stream size for one encode() call. */
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n);
 

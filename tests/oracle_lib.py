@@ -80,6 +80,11 @@ def _load_oracle():
     lib.ans_oracle_prelude_hints.argtypes = [_u8p, _u32p]
     lib.ans_oracle_bound.restype = C.c_size_t
     lib.ans_oracle_bound.argtypes = [C.c_int, C.c_uint32, C.c_size_t]
+    lib.ans_oracle_blocks_digest.restype = C.c_int
+    lib.ans_oracle_blocks_digest.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _u32p, _u64p, _u64p,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.ans_oracle_hash_spans.restype = None
+    lib.ans_oracle_hash_spans.argtypes = [_u8p, _u64p, C.c_size_t, C.c_int, _u64p]
     return lib
 
 
@@ -141,6 +146,52 @@ def have_ref():
 
 
 # ---------------------------------------------------------------- convenience wrappers
+
+def host_threads():
+    """Threads a whole-list oracle pass may use: the affinity mask, capped at 32."""
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
+
+
+def oracle_blocks_digest(kind, f, data, block_ints, ckpt_interval, threads=None):
+    """Every block of `data` through the oracle on native threads: (sizes u32[nb], stream hashes u64[nb], restart-point
+    digests u64[nb], max log2 frame, max alphabet).  See ans_oracle.h."""
+    data = np.ascontiguousarray(data, dtype=np.uint32)
+    nb = (data.size + block_ints - 1) // block_ints
+    sizes = np.zeros(nb, dtype=np.uint32)
+    sh = np.zeros(nb, dtype=np.uint64)
+    cd = np.zeros(nb, dtype=np.uint64)
+    lg, ns = C.c_uint32(0), C.c_uint32(0)
+    rc = oracle().ans_oracle_blocks_digest(kind, f, data, data.size, block_ints, ckpt_interval, threads or host_threads(), sizes, sh, cd,
+                                           C.byref(lg), C.byref(ns))
+    if rc != 0:
+        raise RuntimeError("oracle block pass failed")
+    return sizes, sh, cd, lg.value, ns.value
+
+
+def hash_spans(buf, offs, threads=None):
+    """ans_oracle_hash of every span [offs[i], offs[i + 1]) of the byte buffer."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    out = np.zeros(offs.size - 1, dtype=np.uint64)
+    oracle().ans_oracle_hash_spans(buf, offs, offs.size - 1, threads or host_threads(), out)
+    return out
+
+
+def ckpt_digest(states, offs):
+    """The restart-point digest of ans_oracle_blocks_digest from parsed arrays: states [nb, k, 4] u64, offs [nb, k] u32
+    (unused slots zero: they add nothing)."""
+    nb, k = offs.shape
+    with np.errstate(over="ignore"):
+        s_idx = np.arange(k, dtype=np.uint64)
+        w_state = (np.uint64(2654435761) + np.uint64(2) * (np.uint64(4) * s_idx[:, None] + np.arange(4, dtype=np.uint64)[None, :]))
+        w_off = np.uint64(40503) + np.uint64(2) * s_idx
+        d = (states.astype(np.uint64) * w_state[None, :, :]).sum(axis=(1, 2), dtype=np.uint64)
+        d = d + (offs.astype(np.uint64) * w_off[None, :]).sum(axis=1, dtype=np.uint64)
+    return d
+
 
 def ref_bwtmtf(T, n):
     """src/generate_bwtmtf.cpp:142-173 on the parsed text T (ints, terminated by 0) through oracle/_ref: the reference's

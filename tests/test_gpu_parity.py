@@ -1307,6 +1307,53 @@ def test_full_size_configs_roundtrip_and_spot_blocks(A, ctx, kind, f, spec):
         assert np.array_equal(parts["ckpt_off"][b][:k], off) and np.array_equal(parts["ckpt_state"][b][:k], st), (spec, b)
 
 
+@pytest.mark.parametrize("kind,f,spec,mi", [(ol.FOLD, 1, "zipf20s1.2", 256), (ol.FOLD, 3, "zipf24s1.2", 256), (ol.RFOLD, 3, "zipf24s1.2", 48),
+                                            (ol.FOLD, 1, "uniform1-256", 96), (ol.FOLD, 5, "zipf20s1.2", 64)])
+def test_full_size_every_block_equals_oracle(A, ctx, kind, f, spec, mi):
+    """Round 4: full-size parity that is not a sample.  BASELINE config 2 at its 256 Mi ints, config 3a at 256 Mi,
+    3b at 48 Mi (the oracle's ANSrfold pass is the slow side), config 1's shape, the harness's fidelity 5: EVERY block's stream
+    (size and 64-bit hash), EVERY restart point (digest) and the header's frame / alphabet bounds are compared with the oracle,
+    which encodes all blocks on the host's cores (ans_oracle_blocks_digest); then the device round trip."""
+    import torch
+
+    n = mi * (1 << 20) + (12345 if mi < 256 else 0)
+    block, ck = 16384, 1024
+    d_in = torch.empty(n, dtype=torch.int32, device="cuda")
+    A.generate_dev(ctx, spec, d_in.data_ptr(), n, seed=4242)
+    codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ck)
+    d_out = torch.empty(min(codec.bound(n), 8 * n + (64 << 20)), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for call in range(2):  # the geometry's first call (discovery) and a hinted one must write the same container
+        nb = codec.encode_dev(d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel())
+        cont = d_out[:nb].cpu().numpy()
+        if call == 0:
+            first = cont.copy()
+        else:
+            assert np.array_equal(cont, first)
+    del first
+    host = d_in.cpu().numpy().view(np.uint32)
+    sizes, shash, cdig, lg, ns = ol.oracle_blocks_digest(kind, f, host, block, ck)
+    del host
+    parts = A.parse_container(cont)
+    H = parts["header"]
+    nblocks = (n + block - 1) // block
+    assert H.n == n and H.nblocks == nblocks and H.payload_offset + H.payload_bytes == nb
+    assert H.max_log2_frame == lg and H.max_nsyms == ns
+    boff = parts["block_off"].astype(np.uint64)
+    assert np.array_equal(np.diff(boff).astype(np.uint32), sizes)
+    got_hash = ol.hash_spans(cont, boff + np.uint64(H.payload_offset))
+    bad = np.nonzero(got_hash != shash)[0]
+    assert bad.size == 0, (spec, "first differing blocks", bad[:8])
+    got_dig = ol.ckpt_digest(parts["ckpt_state"], parts["ckpt_off"])
+    bad = np.nonzero(got_dig != cdig)[0]
+    assert bad.size == 0, (spec, "restart points differ in blocks", bad[:8])
+    del parts, cont
+    d_back = torch.zeros(n, dtype=torch.int32, device="cuda")
+    codec.decode_dev(d_out.data_ptr(), nb, d_back.data_ptr(), n)
+    assert bool(torch.equal(d_back, d_in))
+    assert ctx.last_encode_stats()["near_threshold_decisions"] == 0
+
+
 @pytest.mark.parametrize("mi", [180, 250])
 def test_encoder_multi_wave_workgroups_with_ragged_end(A, ctx, mi):
     """The encoder packs 3 resp. 4 waves into a workgroup at these sizes and keeps them in step with a barrier --

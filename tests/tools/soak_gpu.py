@@ -38,7 +38,7 @@ def gen(kind, n):
     if c == 7: return rng.geometric(0.001, size=n).astype(np.uint32)
     return ol.gen_inputs("zipf20s1.2", n, seed=int(rng.integers(1, 1 << 30)))
 blocks = [(16384, 1024), (16384, 256), (4096, 512), (65536, 1024), (8192, 2048), (16448, 1028), (1024, 64), (32768, 4096), (2052, 4), (16384, 16384)]
-t0 = time.time(); it = 0; fails = 0; near = 0
+t0 = time.time(); it = 0; fails = 0; near = 0; pc = 0
 while time.time() - t0 < budget:
     it += 1
     CODECS = [(ol.FOLD, 1), (ol.FOLD, 1), (ol.FOLD, 3), (ol.FOLD, 5), (ol.RFOLD, 1), (ol.RFOLD, 3), (ol.MSB, 0), (ol.INT, 0)]
@@ -56,7 +56,9 @@ while time.time() - t0 < budget:
     else: codec = A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt) if kind == ol.MSB else cls(f, ctx=ctx, block_ints=block, ckpt_interval=ckpt)
     try:
         cont = codec.encode(data)
-        near += ctx.last_encode_stats()["near_threshold_decisions"]
+        st_ = ctx.last_encode_stats()
+        near += st_["near_threshold_decisions"]
+        pc += 1 if st_["path"] & 128 else 0  # the producer / consumer encoder kernel ran (round 4)
         out = codec.decode(cont, n)
         ok = np.array_equal(out, data)
         if ok and n <= 300000 and it % 3 == 0:   # oracle parity of every block stream (CPU cost)
@@ -78,6 +80,6 @@ while time.time() - t0 < budget:
     if it % 50 == 0: print("it", it, "elapsed %.0f s" % (time.time() - t0), "fails", fails); sys.stdout.flush()
 # frame-size decisions within 1e-12 (relative) of the 1.001 H threshold: the only place where the portable log2
 # could in principle decide differently from glibc's; expected 0
-print("SOAK done: iterations", it, "fails", fails, "near_threshold_decisions", near)
+print("SOAK done: iterations", it, "fails", fails, "near_threshold_decisions", near, "calls through k_encode_pc", pc)
 assert near == 0, "near-threshold frame-size decisions seen: compare those blocks with the reference"
 sys.exit(1 if fails else 0)

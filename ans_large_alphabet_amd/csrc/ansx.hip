@@ -101,6 +101,7 @@ struct ansx_ctx {
         bool encode_mode2 = false;    // ANSX_ENCODE_MODE2: the compact-table encoder (k_encode<2>) even where the tables fit LDS (tests)
         bool force_pc = false;        // ANSX_FORCE_PC: the pair kernel for every workgroup of 64 full blocks, however few (tests)
         bool no_pc = false;           // ANSX_NO_PC: the LDS-table encoder as one wave per 16 blocks everywhere (k_encode<1>), no producer / consumer pairs
+        int decode_small_ring = 0;    // ANSX_DECODE_SMALL_RING: "never" / "always" (default: by the container's bytes per int)
         int decode_pair = 0;          // ANSX_DECODE_PAIR: "0"/unset auto, "never", "always" (k_decode_rank2: two blocks per workgroup)
         u32 pair_lds_limit = 0;       // ANSX_DECODE_PAIR_LDS: auto uses the pair kernel up to this many bytes of LDS per workgroup (0: never --
                                       // measured SLOWER than one block per workgroup, 0.77-0.79 vs 0.72 ms on the headline workload)
@@ -1274,11 +1275,25 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
                     (const uint4*)c->dec_info.p, gflags);
                 return ANSX_OK;
             }
+            // Streams of a few bytes per step (the container's bytes per int, header fields only): the 256-byte speculative
+            // rings -- sixteen instead of ten blocks of the headline workload per CU; an interval that outran its window is
+            // decoded again (dec_segments_ring_small), so a wrong guess here costs time, never correctness.
+            const int small = c->dbg.decode_small_ring;  // tests: 1 never, 2 always
+            const bool lean = g.n != 0 && (double)(cont_bytes - payload_off) / (double)g.n <= 2.0 && g.ckpt % 16 == 0;
+            if (small != 1 && (small == 2 || lean)) {
+                const size_t ldss = rs_tables + (size_t)(threads / 4) * ANSX_SRING_STRIDE + 16;
+                if (ldss > 48 * 1024)
+                    HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
+                LAUNCH(c, "k_decode", (k_decode_rank<RF, 2>), g.nblocks, threads, ldss, s, cont, g, NSP, boff,
+                    ck_state, ck_off, payload_off, d_out, maxM, max_ep, (u64)cont_bytes, (const u32*)c->dec_cum.p,
+                    (const uint4*)c->dec_info.p, gflags);
+                return ANSX_OK;
+            }
             const size_t lds = rs_tables + ring_lds;
             if (lds > 48 * 1024)
-                HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, true>,
+                HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LAUNCH(c, "k_decode", (k_decode_rank<RF, true>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
+            LAUNCH(c, "k_decode", (k_decode_rank<RF, 1>), g.nblocks, threads, lds, s, cont, g, NSP, boff,
                 ck_state, ck_off, payload_off, d_out, maxM, max_ep, (u64)cont_bytes, (const u32*)c->dec_cum.p,
                 (const uint4*)c->dec_info.p, gflags);
             return ANSX_OK;
@@ -1290,9 +1305,9 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
             stream_cap = (u32)want_stream;
         }
         if (lds > 48 * 1024)
-            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, false>,
+            HIPCHK(c, hipFuncSetAttribute((const void*)k_decode_rank<RF, 0>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LAUNCH(c, "k_decode", (k_decode_rank<RF, false>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
+        LAUNCH(c, "k_decode", (k_decode_rank<RF, 0>), g.nblocks, threads, lds, s, cont, g, NSP, boff, ck_state,
             ck_off, payload_off, d_out, maxM, max_ep, (u64)stream_cap, (const u32*)c->dec_cum.p,
             (const uint4*)c->dec_info.p, gflags);
         return ANSX_OK;
@@ -1716,6 +1731,8 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NO_PC_AUTO")) c->dbg.no_pc_auto = on;
     else if (!strcmp(name, "ANSX_PC_B_PAIRS")) c->dbg.pc_b_pairs = (value && value[0] == '1') ? 1u : 2u;
     else if (!strcmp(name, "ANSX_ENCODE_MODE2")) c->dbg.encode_mode2 = on;
+    else if (!strcmp(name, "ANSX_DECODE_SMALL_RING"))
+        c->dbg.decode_small_ring = !value ? 0 : !strcmp(value, "never") ? 1 : !strcmp(value, "always") ? 2 : 0;
     else if (!strcmp(name, "ANSX_DECODE_PAIR"))
         c->dbg.decode_pair = !value ? 0 : !strcmp(value, "never") ? 1 : !strcmp(value, "always") ? 2 : 0;
     else if (!strcmp(name, "ANSX_DECODE_PAIR_LDS")) c->dbg.pair_lds_limit = (value && value[0]) ? (u32)strtoul(value, nullptr, 10) : 0u;

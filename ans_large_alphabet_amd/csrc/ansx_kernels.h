@@ -3200,6 +3200,8 @@ __global__ __launch_bounds__(256) void k_parse_prelude_par(const u8* __restrict_
 #define ANSX_DEC_SCRATCH 96u  // k_decode_rank: scan scratch + error flag between the tables and the stream area
 #define ANSX_RING_BYTES (128 * ANSX_RING_CHK)
 #define ANSX_RING_STRIDE (ANSX_RING_BYTES + 16)  // + 8 mirror bytes (ring bytes 0..7 once more) and padding to 16
+#define ANSX_SRING_BYTES 256                       // the speculative small ring (round 4), see dec_segments_ring_small
+#define ANSX_SRING_STRIDE (ANSX_SRING_BYTES + 16)
 // end8 = end - 8: the decoder keeps its cursor biased by 8, so this is what its prefix sum yields
 template <int MODE>
 __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u32* lds_stream, int end8)
@@ -3220,6 +3222,17 @@ __device__ __forceinline__ u64 dec_fetch8(const u8* __restrict__ stream, const u
         const u32 rb = (u32)(size_t)(__attribute__((address_space(3))) const void*)lds_stream;
         const u32 a = (u32)end8;
         lds_cu32* wp = (lds_cu32*)(size_t)(rb + (a & (ANSX_RING_BYTES - 4)));
+        const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        const u32 sh = a & 3;
+        const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        return ((u64)hi << 32) | lo;
+    } else if (MODE == 3) {
+        // the 256-byte speculative ring (dec_segments_ring_small): as MODE 2 with that ring's mask
+        typedef __attribute__((address_space(3))) const u32 lds_cu32;
+        const u32 rb = (u32)(size_t)(__attribute__((address_space(3))) const void*)lds_stream;
+        const u32 a = (u32)end8;
+        lds_cu32* wp = (lds_cu32*)(size_t)(rb + (a & (ANSX_SRING_BYTES - 4)));
         const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
         const u32 sh = a & 3;
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
@@ -3337,7 +3350,7 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     q = __builtin_amdgcn_sad_u8(S, 0u, q);
     // a corrupt stream can drive the cursor below 0: the ring wraps every address into itself, the
     // other sources have 8 guard bytes in front and clamp
-    if (STREAM_LDS != 2) myp8 = myp8 < -8 ? -8 : myp8;
+    if (STREAM_LDS != 2 && STREAM_LDS != 3) myp8 = myp8 < -8 ? -8 : myp8;
     const u64 v = dec_fetch8<STREAM_LDS>(stream, lds_stream, myp8);
     const u32 hi = (u32)(v >> 32), lo = (u32)v;
     if constexpr (LUT::WIDE) {
@@ -3425,6 +3438,38 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                 if (ql == 3) o[i] = val;
             }
         }
+    }
+}
+
+// 4 x 4 transpose inside a quad: lane l (0..3 within its quad) holds v[u] = ITS value of step u and ends with
+// v[c] = lane c's value of step l -- the four neighbouring output ints of step l -- so that an interval's outputs leave as
+// ONE 16-byte store per lane (a quad writes 64 contiguous bytes) instead of four 4-byte stores 16 bytes apart per step.
+// (The decoder's scattered dword stores -- 16 partial 16-byte writes per wave and step -- were a third of its time: 0.72 ms
+// with them, 0.48 with the same stores aimed at one address)  Butterfly: elements u and
+// u ^ 1 between lanes l and l ^ 1 where bit 0 of u and l differ, then u and u ^ 2 between l and l ^ 2 on bit 1.
+__device__ __forceinline__ void quad_transpose4(u32 (&v)[4], u32 ql)
+{
+    const bool o1 = (ql & 1u) != 0, o2 = (ql & 2u) != 0;
+    u32 a[4];
+    {
+        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[0], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[1], 0xB1, 0xF, 0xF, true);
+        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[2], 0xB1, 0xF, 0xF, true);
+        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[3], 0xB1, 0xF, 0xF, true);
+        a[0] = o1 ? x1 : v[0];
+        a[1] = o1 ? v[1] : x0;
+        a[2] = o1 ? x3 : v[2];
+        a[3] = o1 ? v[3] : x2;
+    }
+    {
+        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[0], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[1], 0x4E, 0xF, 0xF, true);
+        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[2], 0x4E, 0xF, 0xF, true);
+        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[3], 0x4E, 0xF, 0xF, true);
+        v[0] = o2 ? x2 : a[0];
+        v[1] = o2 ? x3 : a[1];
+        v[2] = o2 ? a[2] : x0;
+        v[3] = o2 ? a[3] : x1;
     }
 }
 
@@ -3543,6 +3588,7 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
             }
         }
         u32* op = o + seg * g.ckpt + ql;
+        u32* ob = o + seg * g.ckpt;  // (16-byte aligned: the output buffer is, and block_ints and the interval are multiples of 4)
         bool pending = false;
         ansx_u32x4 rr[NP];
 #pragma unroll
@@ -3559,22 +3605,184 @@ __device__ __forceinline__ void dec_segments_ring(const ansx_geo& g, u32 b, u32 
         u32 i = 0;
         for (; i + CHK <= steps; i += CHK) {
             // ---- check: land the previous request, decide the next one
-            if constexpr (CHK == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
+            // (exactly ONE operation is younger than the request: the previous interval's 16-byte output store)
+            if constexpr (CHK == 4) asm volatile("s_waitcnt vmcnt(1)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
             else asm volatile("s_waitcnt vmcnt(2)" : "+v"(rr[0])::"memory");
             land();
             const int cur = ANSX_DEC_P(q);
             pending = (cur - lo) < T;
 #pragma unroll
             for (int j = 0; j < NP; j++) rr[j] = ring_load16(D, lo - R + lane_off + 16 * j, pending);
+            if constexpr (CHK == 4) {
+                u32 v4[4];
 #pragma unroll
-            for (u32 u = 0; u < (u32)CHK; u++)
-                op[4 * (i + u)] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+                for (u32 u = 0; u < 4; u++) v4[u] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+                quad_transpose4(v4, ql);  // lane ql: the four ints of step i + ql
+                *(ansx_u32x4*)(ob + 4 * (i + ql)) = ansx_u32x4{ v4[0], v4[1], v4[2], v4[3] };
+            } else {
+#pragma unroll
+                for (u32 u = 0; u < (u32)CHK; u++)
+                    op[4 * (i + u)] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+            }
         }
         // leftover steps (restart interval not a multiple of 4*CHK): land what is in flight first
         if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1])::"memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0])::"memory");
         land();
         for (; i < steps; i++) op[4 * i] = dec_step<2>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+    }
+}
+
+// ---- per-quad stream ring, 256 bytes, speculative (round 4) -------------------------------------------------------
+// The 512-byte ring above is sized for the format's worst case -- 28 stream bytes per step, every step -- and is 8.4 of the
+// 15 KB of LDS a block of the headline workload needs: ten blocks per CU, and the decoder is bound by how many chains a CU
+// holds.  Lists whose streams average a few bytes per step (1.1 bytes per int on the headline
+// workload: 4.4 per step) never come near that.  This form keeps a 256-byte window (sixteen blocks per CU) and does NOT
+// guarantee that an interval's reads stay inside it: it CHECKS, after every interval of CHK = 4 steps, that the cursor is
+// still at least 16 bytes above the window's low end -- every byte an interval reads lies at most 11 below its final cursor --
+// and otherwise takes the interval back: states and cursor as saved at its start, a full window loaded synchronously below
+// that cursor (at least 225 bytes: more than the 112 + 16 an interval can need), the four steps again (their output stores
+// are idempotent).  R = 128 more bytes are requested when at most 128 remain below the cursor -- they land one check later,
+// when at most 128 remain for certain, so they only replace consumed bytes -- and an interval can only fail if the one before
+// it and itself consumed more than 112 bytes together: never on such lists, every interval on a list of 30-bit values with
+// three exception bytes each (the host chooses this form by the container's bytes per int; correctness does not depend on it).
+struct dec_sring_pre {
+    u64 st;
+    int p, lo;
+    ansx_u32x4 r[ANSX_SRING_BYTES / 64];
+};
+__device__ __forceinline__ int dec_sring_lo(int p) { return (p - 225) & ~31; }  // p - lo in [225, 256]
+__device__ __forceinline__ void dec_sring_prefetch(dec_sring_pre& P, const ansx_geo& g, u32 b, u32 sbytes, u32 tid,
+    u32 logM, const u8* __restrict__ stream, const dec_ring_desc& D, const u64* __restrict__ ckpt_state,
+    const u32* __restrict__ ckpt_off)
+{
+    constexpr int RB = ANSX_SRING_BYTES;
+    const u32 seg = tid >> 2, ql = tid & 3;
+    const u32 nseg = g.block_ints / g.ckpt;
+    P.st = 0;
+    P.p = 0;
+    if (seg == 0) {  // ans_fold.hpp:289-295: states 3,2,1,0 from the end
+        P.st = ld_u64_unaligned(stream + sbytes - 32 + 8 * (3 - ql)) + ((u64)16 << logM);
+        P.p = (int)sbytes - 32;
+    } else if (seg < nseg) {
+        const u64 idx = (u64)b * g.nckf + (seg - 1);
+        u32 po;
+        ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &P.st, &po);
+        P.p = (int)(po < sbytes ? po : sbytes);
+    }
+    P.lo = dec_sring_lo(P.p);
+#pragma unroll
+    for (int j = 0; j < RB / 64; j++) P.r[j] = ring_load16(D, P.lo + (RB / 4) * (int)ql + 16 * j, seg < nseg);
+}
+
+template <typename LUT>
+__device__ __forceinline__ void dec_segments_ring_small(const ansx_geo& g, u32 b, u32 sbytes, u32 tid, u32 nt,
+    u32 logM, const LUT& lut, const u8* __restrict__ stream, u32* rings, const dec_ring_desc& D,
+    const u64* __restrict__ ckpt_state, const u32* __restrict__ ckpt_off, u32* __restrict__ o, dec_sring_pre& P)
+{
+    constexpr int RB = ANSX_SRING_BYTES, CHK = 4;
+    constexpr int R = 128;             // bytes per refill, 32 per lane
+    constexpr int NP = 2;              // 16-byte pieces per lane and refill
+    constexpr int T = 128;             // request when at most this much remains below the cursor
+    constexpr int MARGIN = 16;         // an interval that ends with less than this below its cursor is taken back
+    const u32 nseg = g.block_ints / g.ckpt;  // uniform segments (checked by the caller)
+    const u32 nq = nt >> 2, quad = tid >> 2, ql = tid & 3;
+    const dec_quad_const qc = dec_make_qc(ql);
+    const u64 Lb = (u64)16 << logM;
+    const u32 mask = (1u << logM) - 1;
+    u32* ring = rings + quad * (ANSX_SRING_STRIDE / 4);
+    u8* ring8 = (u8*)ring;
+    const u32 steps = g.ckpt >> 2;
+    const int lane_off = (R / 4) * (int)ql;  // this lane's share of a refill
+    for (u32 seg = quad; seg < nseg; seg += nq) {
+        u64 st;
+        int p, lo;
+        ansx_u32x4 r[RB / 64];
+        if (seg == quad) {  // the quad's first segment: requested by dec_sring_prefetch before the table build
+            st = P.st;
+            p = P.p;
+            lo = P.lo;
+#pragma unroll
+            for (int j = 0; j < RB / 64; j++) r[j] = P.r[j];
+        } else {
+            const u64 idx = (u64)b * g.nckf + (seg - 1);  // (seg >= nq > 0)
+            u32 po;
+            ckpt_load(g, ckpt_state, ckpt_off, idx, 3 - ql, &st, &po);
+            p = (int)(po < sbytes ? po : sbytes);
+            lo = dec_sring_lo(p);
+#pragma unroll
+            for (int j = 0; j < RB / 64; j++) r[j] = ring_load16(D, lo + (RB / 4) * (int)ql + 16 * j, true);
+        }
+        u32 q = ANSX_DEC_Q(p);
+        // the whole window [lo, lo + RB): RB / 64 pieces per lane, written once they have landed
+        auto fill = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < RB / 64; j++) {
+                asm volatile("" : "+v"(r[j]));  // keep the dependence on the asm loads behind the wait
+                const u32 d = (u32)(lo + (RB / 4) * (int)ql + 16 * j) & (RB - 1);
+                *(ansx_u32x4*)(ring8 + d) = r[j];
+                if (d == 0) *(uint2*)(ring8 + RB) = make_uint2(r[j].x, r[j].y);  // second copy of ring bytes 0..7
+            }
+        };
+        fill();
+        u32* op = o + seg * g.ckpt + ql;
+        u32* ob = o + seg * g.ckpt;
+        bool pending = false;
+        ansx_u32x4 rr[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) rr[j] = ansx_u32x4{ 0u, 0u, 0u, 0u };
+        auto land = [&]() {
+            if (pending) {
+                lo -= R;
+                const u32 d0 = (u32)(lo + lane_off) & (RB - 1);
+#pragma unroll
+                for (int j = 0; j < NP; j++) *(ansx_u32x4*)(ring8 + d0 + 16 * j) = rr[j];  // aligned share: no wrap inside
+                if (d0 == 0) *(uint2*)(ring8 + RB) = make_uint2(rr[0].x, rr[0].y);
+            }
+        };
+        // a full window below cursor position p0, synchronously (the rare paths)
+        auto refill_at = [&](int p0) {
+            lo = dec_sring_lo(p0);
+#pragma unroll
+            for (int j = 0; j < RB / 64; j++) r[j] = ring_load16(D, lo + (RB / 4) * (int)ql + 16 * j, true);
+            fill();
+            pending = false;
+        };
+        u32 i = 0;
+        for (; i + CHK <= steps; i += CHK) {
+            // ---- check: land the previous request (exactly the interval's CHK output stores are younger), decide the next
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");  // (younger: the previous interval's one store)
+            land();
+            pending = (ANSX_DEC_P(q) - lo) <= T;
+#pragma unroll
+            for (int j = 0; j < NP; j++) rr[j] = ring_load16(D, lo - R + lane_off + 16 * j, pending);
+            const u64 st0 = st;
+            const u32 q0 = q;
+            u32 v4[4];
+#pragma unroll
+            for (u32 u = 0; u < (u32)CHK; u++) v4[u] = dec_step<3>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+            if (__builtin_amdgcn_ballot_w64((ANSX_DEC_P(q) - lo) < MARGIN) != 0) {
+                // some quad of the wave may have read below its window: the whole wave takes the interval back (a quad that
+                // was fine repeats the same four steps from the same state)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
+                st = st0;
+                q = q0;
+                refill_at(ANSX_DEC_P(q0));
+#pragma unroll
+                for (int j = 0; j < NP; j++) rr[j] = ansx_u32x4{ 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (u32 u = 0; u < (u32)CHK; u++) v4[u] = dec_step<3>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+            }
+            quad_transpose4(v4, ql);  // lane ql: the four ints of step i + ql, one 16-byte store (see quad_transpose4)
+            *(ansx_u32x4*)(ob + 4 * (i + ql)) = ansx_u32x4{ v4[0], v4[1], v4[2], v4[3] };
+        }
+        // leftover steps (restart interval not a multiple of 16 ints): behind a full window, whatever is in flight dropped
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[NP - 1])::"memory");
+        if (i < steps) {
+            refill_at(ANSX_DEC_P(q));
+            for (; i < steps; i++) op[4 * i] = dec_step<3>(st, q, true, qc, logM, mask, Lb, lut, stream, ring);
+        }
     }
 }
 
@@ -3699,7 +3907,8 @@ __device__ __forceinline__ bool dec_build_rank_tables(const ansx_geo& g, u32* bw
 //
 // k_decode_rank: frames up to 2^16, rank/select tables in LDS (the normal path).
 // RING: per-quad stream rings instead of the staged stream (stream_cap is then the container size).
-template <bool RFOLD, bool RING>
+// RING: 0 = staged stream (or straight from HBM), 1 = per-quad 512-byte rings, 2 = per-quad 256-byte speculative rings
+template <bool RFOLD, int RING>
 __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     const u64* __restrict__ block_off, const u64* __restrict__ ckpt_state,
     const u32* __restrict__ ckpt_off, u64 payload_off, u32* __restrict__ outp, u32 maxM,
@@ -3744,7 +3953,7 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
     // full block: all segments have g.ckpt ints (host-checked), each quad's first one is requested now
     const bool use_ring = RING && nb == g.block_ints;
     dec_ring_desc D;
-    dec_ring_pre RP;
+    typename std::conditional<RING == 2, dec_sring_pre, dec_ring_pre>::type RP;
     if (use_ring) {
         // buffer view of this block's stream with up to 1 KB in front of it (the initial window and
         // the guard bytes reach below offset 0) and 64 bytes behind, clipped to the container
@@ -3756,7 +3965,8 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         if (span > room) span = room;
         const u64 ba = (u64)(uintptr_t)base;
         D.rsrc = ansx_u32x4{ (u32)ba, (u32)(ba >> 32) & 0xFFFFu, (u32)span, 0x00020000u };
-        dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
+        if constexpr (RING == 2) dec_sring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
+        else if constexpr (RING == 1) dec_ring_prefetch(RP, g, b, sbytes, tid, logM, stream, D, ckpt_state, ckpt_off);
     }
     for (u32 w = tid; w < W; w += nt) bwp[w] = make_uint2(0u, 0u);
     if (tid == 0) {
@@ -3779,7 +3989,8 @@ __global__ void k_decode_rank(const u8* __restrict__ cont, ansx_geo g, u32 NSP,
         // rings start at the next 16-byte boundary of the LDS address space (the host adds the slack)
         const u32 labs = (u32)(size_t)(__attribute__((address_space(3))) void*)lds_stream;
         u32* rings = lds_stream + ((((labs + 15u) & ~15u) - labs) >> 2);
-        dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o, RP);
+        if constexpr (RING == 2) dec_segments_ring_small(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o, RP);
+        else if constexpr (RING == 1) dec_segments_ring(g, b, sbytes, tid, nt, logM, lut, stream, rings, D, ckpt_state, ckpt_off, o, RP);
     } else if (st_lds)
         dec_segments<true>(g, b, nb, sbytes, tid, nt, logM, lut, stream, lds_stream, ckpt_state, ckpt_off, o);
     else

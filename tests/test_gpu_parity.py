@@ -810,7 +810,9 @@ def test_decoder_stream_modes(A, ctx, kind, f):
         for env in ({}, {"ANSX_DECODE_MODE": "ring"}, {"ANSX_DECODE_MODE": "staged"},
                     {"ANSX_DECODE_MODE": "staged", "ANSX_NO_STREAM_LDS": "1"}, {"ANSX_DECODE_TABLE": "1"},
                     # ring decoder: one block per workgroup (k_decode_rank) / two blocks in one instruction stream (k_decode_rank2)
-                    {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_PAIR": "never"}, {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_PAIR": "always"}):
+                    {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_PAIR": "never"}, {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_PAIR": "always"},
+                    # 512-byte worst-case rings / 256-byte speculative rings (chosen by the container's bytes per int otherwise)
+                    {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_SMALL_RING": "never"}, {"ANSX_DECODE_MODE": "ring", "ANSX_DECODE_SMALL_RING": "always"}):
             try:
                 for k, v in env.items():
                     ctx.debug_set(k, v)
@@ -818,6 +820,32 @@ def test_decoder_stream_modes(A, ctx, kind, f):
             finally:
                 for k in env:
                     ctx.debug_set(k, None)
+
+
+def test_small_ring_decoder_takes_intervals_back(A, ctx):
+    """k_decode_rank<.., 2> (round 4): 256-byte stream rings that do not guarantee an interval's reads stay inside the window
+    -- the kernel checks after every four steps and decodes the interval again behind a full window.  Forced onto lists
+    that consume up to 28 bytes per step (30-bit values: three exception bytes and a renormalisation word almost every
+    symbol), where nearly every interval is taken back, and onto mixtures; restart intervals that leave leftover steps."""
+    rng = np.random.default_rng(8)
+    n = 5 * 16384 + 1000
+    heavy = rng.integers(1 << 24, 1 << 30, size=n, dtype=np.uint32)
+    mixed = np.where(rng.random(n) < 0.9, rng.integers(0, 200, size=n), rng.integers(1 << 24, 1 << 30, size=n)).astype(np.uint32)
+    bursts = ol.gen_inputs("zipf20s1.2", n, seed=3).copy()
+    for a in range(0, n - 200, 3000):  # stretches of maximal consumption inside an otherwise lean stream
+        bursts[a:a + 160] = rng.integers(1 << 29, 1 << 30, size=160, dtype=np.uint32)
+    for data in (heavy, mixed, bursts):
+        for kind, f, block, ck in ((ol.FOLD, 1, 16384, 1024), (ol.RFOLD, 1, 8192, 256), (ol.FOLD, 3, 16384, 1028 - 4), (ol.MSB, 0, 4096, 64)):
+            d = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7)))) if kind == ol.RFOLD else data
+            codec = codec_for(A, ctx, kind, f, block_ints=block, ckpt_interval=ck)
+            cont = codec.encode(d)
+            try:
+                ctx.debug_set("ANSX_DECODE_MODE", "ring")
+                ctx.debug_set("ANSX_DECODE_SMALL_RING", "always")
+                assert np.array_equal(codec.decode(cont, n), d), (kind, f, block, ck)
+            finally:
+                ctx.debug_set("ANSX_DECODE_MODE", None)
+                ctx.debug_set("ANSX_DECODE_SMALL_RING", None)
 
 
 def test_random_geometries_round_trip_and_match_oracle(A, ctx):

@@ -419,8 +419,10 @@ static int launch_f64_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32
         pairs = 4, S = 8;                                                    // (A) on request
     else if (pc_geo && !mode1 && pc_lds(2, 4) <= 160 * 1024 && full_blocks >= 32 && !c->dbg.no_pc_auto)
         pairs = c->dbg.pc_b_pairs, S = 4;                                    // (B) every table entry in LDS, two rounds
-    else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && full_blocks >= 16 && !c->dbg.no_pc_auto)
-        pairs = 1, S = 8;                                                    // (C) short lists
+    else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && full_blocks >= 16 && !c->dbg.no_pc_auto
+        && (c->dbg.force_pc || (NB == full_blocks && NB % 16 == 0)))
+        pairs = 1, S = 8;  // (C) short lists.  Only when no block is left over: a second launch for the rest -- even one block -- takes a
+                           // lone wave's whole 0.48 ms behind this one (measured on the 5.65 M-int list: 0.39 + 0.49 ms instead of 0.48)
     if (pairs && (g.ckpt == 0 || g.ckpt % (4u * S) == 0)) {
         const u32 wgs = full_blocks / (16 * pairs);
         const size_t lds = pc_lds(pairs, S);

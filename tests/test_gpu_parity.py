@@ -1002,7 +1002,7 @@ def test_encoder_producer_consumer_pairs(A):
         c_pc.close()
     # the two shapes the launch site chooses by itself: (C) short lists -- one pair per workgroup -- and (B) alphabets too
     # large for 64 LDS tables per CU whose tables fit at 32 (two pairs per workgroup, batches of 4 steps; BASELINE config 3)
-    auto = [("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3 + 1024 * 2 + 5),    # C: three workgroups + two blocks + a tail
+    auto = [("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3),                    # C: three workgroups (chosen only when no block is left over)
             ("uniform256", ol.MSB, 0, 512, 0, 16 * 512),                           # C: one workgroup, no restart points
             ("zipf24", ol.FOLD, 3, 1024, 256, 32 * 1024 * 2 + 1024 * 3 + 9),        # B: two workgroups + rest through k_encode<2>
             ("zipf24", ol.RFOLD, 3, 2048, 512, 32 * 2048),                         # B: exactly one workgroup

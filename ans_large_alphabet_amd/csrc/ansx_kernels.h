@@ -3367,6 +3367,38 @@ __device__ __forceinline__ u32 dec_step(u64& st, u32& q, bool active, const dec_
     return (pv & ANSX_PV_MASK) + e;
 }
 
+// 4 x 4 transpose inside a quad: lane l (0..3 within its quad) holds v[u] = ITS value of step u and ends with
+// v[c] = lane c's value of step l -- the four neighbouring output ints of step l -- so that an interval's outputs leave as
+// ONE 16-byte store per lane (a quad writes 64 contiguous bytes) instead of four 4-byte stores 16 bytes apart per step.
+// (The decoder's scattered dword stores -- 16 partial 16-byte writes per wave and step -- were a third of its time: 0.72 ms
+// with them, 0.48 with the same stores aimed at one address; DESIGN.md section 6, round 4.)  Butterfly: elements u and
+// u ^ 1 between lanes l and l ^ 1 where bit 0 of u and l differ, then u and u ^ 2 between l and l ^ 2 on bit 1.
+__device__ __forceinline__ void quad_transpose4(u32 (&v)[4], u32 ql)
+{
+    const bool o1 = (ql & 1u) != 0, o2 = (ql & 2u) != 0;
+    u32 a[4];
+    {
+        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[0], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[1], 0xB1, 0xF, 0xF, true);
+        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[2], 0xB1, 0xF, 0xF, true);
+        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[3], 0xB1, 0xF, 0xF, true);
+        a[0] = o1 ? x1 : v[0];
+        a[1] = o1 ? v[1] : x0;
+        a[2] = o1 ? x3 : v[2];
+        a[3] = o1 ? v[3] : x2;
+    }
+    {
+        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[0], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[1], 0x4E, 0xF, 0xF, true);
+        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[2], 0x4E, 0xF, 0xF, true);
+        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[3], 0x4E, 0xF, 0xF, true);
+        v[0] = o2 ? x2 : a[0];
+        v[1] = o2 ? x3 : a[1];
+        v[2] = o2 ? a[2] : x0;
+        v[3] = o2 ? a[3] : x1;
+    }
+}
+
 // decode every segment of one block (one quad of lanes per segment)
 template <bool STREAM_LDS, typename LUT>
 __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u32 sbytes, u32 tid,
@@ -3403,10 +3435,13 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                 // every quad of the wave decodes the same number of groups (all but the wave that
                 // holds a short last segment): scalar trip count, unrolled
                 u32 i = 0;
+                u32* ob = o + start;  // (16-byte aligned: restart intervals and block lengths are multiples of 4 ints)
                 for (; i + 4 <= steps0; i += 4) {
+                    u32 v4[4];
 #pragma unroll
-                    for (u32 u = 0; u < 4; u++)
-                        op[4 * (i + u)] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                    for (u32 u = 0; u < 4; u++) v4[u] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
+                    quad_transpose4(v4, ql);  // one 16-byte store per lane instead of four dwords 16 bytes apart (see quad_transpose4)
+                    *(ansx_u32x4*)(ob + 4 * (i + ql)) = ansx_u32x4{ v4[0], v4[1], v4[2], v4[3] };
                 }
                 for (; i < steps0; i++)
                     op[4 * i] = dec_step<1>(st, q, true, qc, logM, mask, Lb, lut, stream, lds_stream);
@@ -3438,38 +3473,6 @@ __device__ __forceinline__ void dec_segments(const ansx_geo& g, u32 b, u32 nb, u
                 if (ql == 3) o[i] = val;
             }
         }
-    }
-}
-
-// 4 x 4 transpose inside a quad: lane l (0..3 within its quad) holds v[u] = ITS value of step u and ends with
-// v[c] = lane c's value of step l -- the four neighbouring output ints of step l -- so that an interval's outputs leave as
-// ONE 16-byte store per lane (a quad writes 64 contiguous bytes) instead of four 4-byte stores 16 bytes apart per step.
-// (The decoder's scattered dword stores -- 16 partial 16-byte writes per wave and step -- were a third of its time: 0.72 ms
-// with them, 0.48 with the same stores aimed at one address; DESIGN.md section 6, round 4.)  Butterfly: elements u and
-// u ^ 1 between lanes l and l ^ 1 where bit 0 of u and l differ, then u and u ^ 2 between l and l ^ 2 on bit 1.
-__device__ __forceinline__ void quad_transpose4(u32 (&v)[4], u32 ql)
-{
-    const bool o1 = (ql & 1u) != 0, o2 = (ql & 2u) != 0;
-    u32 a[4];
-    {
-        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[0], 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[1], 0xB1, 0xF, 0xF, true);
-        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[2], 0xB1, 0xF, 0xF, true);
-        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)v[3], 0xB1, 0xF, 0xF, true);
-        a[0] = o1 ? x1 : v[0];
-        a[1] = o1 ? v[1] : x0;
-        a[2] = o1 ? x3 : v[2];
-        a[3] = o1 ? v[3] : x2;
-    }
-    {
-        const u32 x0 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[0], 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-        const u32 x1 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[1], 0x4E, 0xF, 0xF, true);
-        const u32 x2 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[2], 0x4E, 0xF, 0xF, true);
-        const u32 x3 = (u32)__builtin_amdgcn_update_dpp(0, (int)a[3], 0x4E, 0xF, 0xF, true);
-        v[0] = o2 ? x2 : a[0];
-        v[1] = o2 ? x3 : a[1];
-        v[2] = o2 ? a[2] : x0;
-        v[3] = o2 ? a[3] : x1;
     }
 }
 

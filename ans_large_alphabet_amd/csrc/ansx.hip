@@ -411,7 +411,7 @@ static int launch_f64_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32
     const u32 rowwords = ((ns_entries + 2u) / 2u) | 1u;  // ns_entries + 1 running sums of 16 bits, an odd number of words per row
     const u32 full_blocks = (u32)(g.n / g.block_ints);
     const u32 enc_waves_all = (NB + 15) / 16;
-    auto pc_lds = [&](u32 pairs, u32 S) { return (size_t)pairs * 16 * rowwords * 4 + (size_t)pairs * 2 * S * 1024; };
+    auto pc_lds = [&](u32 pairs, u32 S) { return (size_t)pairs * 16 * rowwords * 4 + (size_t)pairs * (2 * S * 1024 + (S == 8 ? 16 * 144 : 0)); };
     u32 pairs = 0, S = 0;
     const bool pc_geo = !c->dbg.no_pc && g.block_ints % 128u == 0 && (u64)scr_stride * 16 < 0x40000000ull;
     if (pc_geo && (c->dbg.use_pc || c->dbg.force_pc) && mode1 && pc_lds(4, 8) <= 160 * 1024

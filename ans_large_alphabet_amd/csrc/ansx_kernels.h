@@ -2238,7 +2238,8 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
     const u32 pair = producer ? wv - pairs : wv;
     const u32 wb0 = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * pairs + pair) * 16));  // first block of this pair (uniform)
     u32* const ptab = lds_pc + pair * 16 * rowwords;  // the pair's 16 rows of running sums (u16), rowwords words each
-    u32* const hand = lds_pc + pairs * 16 * rowwords + pair * (2 * S * 64 * 4);
+    constexpr u32 HANDW = 2 * S * 64 * 4 + (S == 8 ? 16 * 36 : 0);  // words per pair: two hand-over buffers (+ the producer's input strips)
+    u32* const hand = lds_pc + pairs * 16 * rowwords + pair * HANDW;
     {
         // Both waves of a pair stage its tables, eight rows each, a row at a time with all loads of a 640-entry piece in
         // flight: cum[0] = 0, cum[s + 1] = base(s) + freq(s) mod 2^16 (the compact entries hold a valid base for absent symbols
@@ -2274,29 +2275,94 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
         const u64 iba = (u64)(uintptr_t)(in + (u64)wb0 * g.block_ints);
         const ansx_u32x4 irs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)iba),
             (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(16u * g.block_ints * 4u), 0x00020000u };
+        const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)ptab + 4 * (lane >> 2) * rowwords;
+        const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
+        const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
+        // one symbol's hand-over entry from its value and the two running sums around its symbol
+        auto entry = [&](u32 x, u32 k, u32 sh, u32 cur, u32 nxt) {
+            const u32 F = (nxt - cur) & 0xFFFFu;
+            const double Fd = (double)F;
+            // 1/F, under-estimated on purpose (enc_tab<true>::getp)
+            const double r0 = __builtin_amdgcn_rcp(Fd);
+            const double rc = __builtin_fma(__builtin_fma(-Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
+            ansx_u32x4 h;
+            h.x = (f64_lo(rc) & ~3u) | k;
+            h.y = f64_hi(rc);
+            h.z = F | (cur << 16);
+            const u32 xs = x >> (sh & 8u);
+            h.w = (x & 0xFFu) | (xs << 16);
+            return h;
+        };
+        auto fold_of = [&](u32 x, u32& k, u32& sh) {
+            if constexpr (POW2) {
+                const u32 d = __builtin_elementwise_sub_sat(c32f, ffbh_u32(x));
+                k = d >> 3;
+                sh = d & 0x18u;
+            } else {
+                k = map_nbytes(f, x);
+                sh = k << 3;
+            }
+            return tbase + 2 * (__umul24(k, f.D) + (x >> sh));
+        };
+        u32 pb = 0;  // batch being produced
+        if constexpr (S == 8) {
+            // Inputs as 16-byte loads: the 8 groups of a batch are 128 contiguous bytes of the quad's block, lane l of the quad
+            // loads bytes [32 l, 32 l + 32) (a quad reads one whole line per batch instead of eight 16-byte pieces of it through
+            // eight instructions), parks them in a 128-byte LDS strip of the quad and every lane picks its dword of each step.
+            // (The decoder's lesson, DESIGN.md section 6 round 4: it is the number of scattered requests that costs, not the bytes.)
+            // Three batches in flight: registers w[(t + 3) % 4] are requested while batch t is produced.
+            u32* const strip = hand + 2 * S * 64 * 4 + 0;  // (the producer's strips follow the pair's two hand-over buffers)
+            const u32 sbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)strip + (lane >> 2) * 144;
+            const u32 vq = (lane >> 2) * g.block_ints * 4 + 32 * ql;  // this lane's 32 bytes of a batch, relative to the batch's lowest group
+            ansx_u32x4 w[4][2];
+            auto request = [&](u32 batch, ansx_u32x4 (&d)[2]) {
+                // groups G - 8 batch - 8 .. G - 8 batch - 1; a batch before the block's first group: an offset in the previous
+                // block or beyond num_records -- never consumed
+                const u32 off = vq + 16u * (G - 8u * batch - 8u);
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d[0]) : "v"(off), "s"(irs) : "memory");
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(d[1]) : "v"(off), "s"(irs) : "memory");
+            };
+            request(0, w[0]);
+            request(1, w[1]);
+            request(2, w[2]);
+            for (u32 sb = 0; sb < G / ANSX_ENC_XB; sb++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    request(pb + 3, w[(t + 3) % 4]);
+                    asm volatile("s_waitcnt vmcnt(6)" : "+v"(w[t][0]), "+v"(w[t][1]) : : "memory");  // three younger requests of two loads
+                    *(lds_x4*)(size_t)(sbase + 32 * ql) = w[t][0];
+                    *(lds_x4*)(size_t)(sbase + 32 * ql + 16) = w[t][1];
+                    u32 xx[8], kk[8], shh[8], cur[8], nxt[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) xx[i] = *(__attribute__((address_space(3))) const u32*)(size_t)(sbase + 16 * (7 - i) + 4 * (3 - ql));
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const u32 la = fold_of(xx[i], kk[i], shh[i]);
+                        cur[i] = *(lds_u16*)(size_t)la;
+                        nxt[i] = *(lds_u16*)(size_t)(la + 2);
+                    }
+                    const u32 hb = hbase + (pb & 1u) * (S * 1024);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) *(lds_x4*)(size_t)(hb + i * 1024) = entry(xx[i], kk[i], shh[i], cur[i], nxt[i]);
+                    pb++;
+                    __syncthreads();
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]) : : "memory");
+            return;
+        }
         // byte offset of group (G - 32), this lane's state, in that view; a group before the block's first one gives an offset
         // inside the previous block or beyond num_records (reads 0): never consumed
         u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (G - ANSX_ENC_XB);
         u32 xa[ANSX_ENC_XB];
-#ifndef ANSX_PC_ABL_NOLOAD
 #define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
-#else
-#define ANSX_XLOAD(dst, voff, j) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(dst) : "v"(lane) : "memory")
-#endif
 #pragma unroll
-        for (int j = 0; j < ANSX_ENC_XB; j++) {
-            xa[j] = j * 17 + lane;
-            ANSX_XLOAD(xa[j], vcur, j);
-        }
+        for (int j = 0; j < ANSX_ENC_XB; j++) ANSX_XLOAD(xa[j], vcur, j);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < ANSX_ENC_XB; i += 8)
             asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
                          "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
-        const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)ptab + 4 * (lane >> 2) * rowwords;
-        const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
-        const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
-        u32 pb = 0;  // batch being produced
         for (u32 sb = 0; sb < G / ANSX_ENC_XB; sb++) {
             const u32 vnext = vcur - 16 * ANSX_ENC_XB;
 #pragma unroll
@@ -2310,43 +2376,20 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
                     else ANSX_XLOAD(xa[e], vnext, e);
                 }
                 // this batch's registers were requested 32 / S - 1 requests ago: 32 - S younger loads are in flight
-                if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                static_assert(S == 4 || S == 8, "");
 #pragma unroll
                 for (int i = 0; i < S; i++) asm volatile("" : "+v"(xa[t * S + i]));
                 u32 kk[S], shh[S], cur[S], nxt[S];
 #pragma unroll
                 for (int i = 0; i < S; i++) {
-                    const u32 x = xa[t * S + i];
-                    if constexpr (POW2) {
-                        const u32 d = __builtin_elementwise_sub_sat(c32f, ffbh_u32(x));
-                        kk[i] = d >> 3;
-                        shh[i] = d & 0x18u;
-                    } else {
-                        kk[i] = map_nbytes(f, x);
-                        shh[i] = kk[i] << 3;
-                    }
-                    const u32 la = tbase + 2 * (__umul24(kk[i], f.D) + (x >> shh[i]));
+                    const u32 la = fold_of(xa[t * S + i], kk[i], shh[i]);
                     cur[i] = *(lds_u16*)(size_t)la;
                     nxt[i] = *(lds_u16*)(size_t)(la + 2);
                 }
                 const u32 hb = hbase + (pb & 1u) * (S * 1024);
 #pragma unroll
-                for (int i = 0; i < S; i++) {
-                    const u32 x = xa[t * S + i];
-                    const u32 F = (nxt[i] - cur[i]) & 0xFFFFu;
-                    const double Fd = (double)F;
-                    // 1/F, under-estimated on purpose (enc_tab<true>::getp)
-                    const double r0 = __builtin_amdgcn_rcp(Fd);
-                    const double rc = __builtin_fma(__builtin_fma(-Fd, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
-                    ansx_u32x4 h;
-                    h.x = (f64_lo(rc) & ~3u) | kk[i];
-                    h.y = f64_hi(rc);
-                    h.z = F | (cur[i] << 16);
-                    const u32 xs = x >> (shh[i] & 8u);
-                    h.w = (x & 0xFFu) | (xs << 16);
-                    *(lds_x4*)(size_t)(hb + i * 1024) = h;
-                }
+                for (int i = 0; i < S; i++) *(lds_x4*)(size_t)(hb + i * 1024) = entry(xa[t * S + i], kk[i], shh[i], cur[i], nxt[i]);
                 pb++;
                 __syncthreads();
             }

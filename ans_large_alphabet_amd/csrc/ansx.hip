@@ -92,12 +92,10 @@ struct ansx_ctx {
         u32 parse_stage_words = 0;    // ANSX_PARSE_STAGE_WORDS: 0 = default
         bool model_fused = false;     // ANSX_MODEL_FUSED: the single LDS-resident model kernel instead of the five tailored ones
         bool model_sync = false;      // ANSX_MODEL_SYNC: always discover the alphabet with the mid-call read-back
-        bool use_pc = false;          // ANSX_USE_PC: k_encode_pc (producer / consumer wave pairs) for calls whose grid fills the chip.  Off by default:
-                                      // measured EQUAL to k_encode<1> on the headline workload (0.708 vs 0.707 ms) -- the pair's 53 vector
-                                      // instructions per symbol fill the SIMD as the lone wave's 44 do
+        bool use_pc = false;          // ANSX_USE_PC: k_encode_pc's chip-filling shape even under ANSX_NO_PC_AUTO
         u32 pc_b_pairs = 2;           // ANSX_PC_B_PAIRS: pairs per workgroup of shape B (2: one workgroup per CU -- 1.04 ms on BASELINE config 3;
                                       // 1: two workgroups per CU, whose waves the dispatcher does not spread as evenly -- 1.21 ms)
-        bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (forms B and C of launch_f64_encoder)
+        bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (shapes A, B, C of launch_f64_encoder)
         bool encode_mode2 = false;    // ANSX_ENCODE_MODE2: the compact-table encoder (k_encode<2>) even where the tables fit LDS (tests)
         bool force_pc = false;        // ANSX_FORCE_PC: the pair kernel for every workgroup of 64 full blocks, however few (tests)
         bool no_pc = false;           // ANSX_NO_PC: the LDS-table encoder as one wave per 16 blocks everywhere (k_encode<1>), no producer / consumer pairs
@@ -414,9 +412,10 @@ static int launch_f64_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32
     auto pc_lds = [&](u32 pairs, u32 S) { return (size_t)pairs * 16 * rowwords * 4 + (size_t)pairs * (2 * S * 1024 + (S == 8 ? 16 * 144 : 0)); };
     u32 pairs = 0, S = 0;
     const bool pc_geo = !c->dbg.no_pc && g.block_ints % 128u == 0 && (u64)scr_stride * 16 < 0x40000000ull;
-    if (pc_geo && (c->dbg.use_pc || c->dbg.force_pc) && mode1 && pc_lds(4, 8) <= 160 * 1024
+    if (pc_geo && (!c->dbg.no_pc_auto || c->dbg.use_pc || c->dbg.force_pc) && mode1 && pc_lds(4, 8) <= 160 * 1024
         && ((full_blocks / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc))
-        pairs = 4, S = 8;                                                    // (A) on request
+        pairs = 4, S = 8;  // (A) the chip-filling form: 0.673 against k_encode<1>'s 0.708 ms on the headline workload since the producer
+                           // loads its inputs 16 bytes at a time (equal before that)
     else if (pc_geo && !mode1 && pc_lds(2, 4) <= 160 * 1024 && full_blocks >= 32 && !c->dbg.no_pc_auto)
         pairs = c->dbg.pc_b_pairs, S = 4;                                    // (B) every table entry in LDS, two rounds
     else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && full_blocks >= 16 && !c->dbg.no_pc_auto

@@ -379,13 +379,13 @@ constexpr int ANSX_RETRY_GENERAL = -1;  // internal: an optimistic assumption di
 constexpr int ANSX_RETRY_WIDE = -2;     // internal: a frame above 2^16 in a call laid out for packed restart points, repeat with wide ones
 
 // K5, f64-state forms (frames <= 2^16, every block's alphabet <= ns_entries).  Three kernels share the call's blocks:
-//   k_encode_pc   producer / consumer wave pairs over the leading workgroups of 16 x pairs FULL blocks, where that form wins:
-//                 (B) alphabets too large for 64 tables per CU whose tables fit at 32 (two pairs, S = 4: every entry in LDS,
-//                 two rounds, each wave alone on its SIMD) -- BASELINE config 3; (C) short lists (one pair per workgroup, at
-//                 most two per CU); (A) on request, the chip-filling form (four pairs)
-//   k_encode<1>   one wave per 16 blocks, 4-byte LDS entries: everything else that fits (BASELINE config 2)
+//   k_encode_pc   producer / consumer wave pairs, 16 x pairs blocks per workgroup, where that form wins: (A) chip-filling calls
+//                 whose tables fit 64 to a CU (four pairs, S = 8) -- BASELINE config 2; (B) alphabets too large for that whose
+//                 tables fit at 32 (two pairs, S = 4: every entry in LDS, two rounds, each wave alone on its SIMD) -- BASELINE
+//                 config 3; (C) short lists (one pair per workgroup, at most two per CU).  It takes ALL blocks of the call: the
+//                 last workgroup pads itself with neutral steps (blocks that do not exist, the partial last block)
+//   k_encode<1>   one wave per 16 blocks, 4-byte LDS entries: geometries the pair kernel does not take
 //   k_encode<2>   compact tables in HBM with the hottest 1151 symbols per block in LDS: alphabets that fit neither
-// The kernels behind k_encode_pc take the blocks it leaves (fewer than a workgroup's worth, the partial last block).
 template <bool POW2, int S>
 static int launch_pc(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32* src, u32 ns_entries, u32 rowwords, u32 pairs, u32 wgs,
     size_t lds, ansx_blk* blk, u64 scr_stride, u64* ck_state, u32* ck_off, u32* enc_sizes, unsigned long long* enc_gsums, hipStream_t s)
@@ -411,19 +411,19 @@ static int launch_f64_encoder(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u32
     const u32 enc_waves_all = (NB + 15) / 16;
     auto pc_lds = [&](u32 pairs, u32 S) { return (size_t)pairs * 16 * rowwords * 4 + (size_t)pairs * (2 * S * 1024 + (S == 8 ? 16 * 144 : 0)); };
     u32 pairs = 0, S = 0;
-    const bool pc_geo = !c->dbg.no_pc && g.block_ints % 128u == 0 && (u64)scr_stride * 16 < 0x40000000ull;
+    // (block_ints <= 2^22: the stand-in for a neutral step of a 2^16 frame lets the state creep by 2^-16 per step, see the kernel)
+    const bool pc_geo = !c->dbg.no_pc && g.block_ints % 128u == 0 && g.block_ints <= (1u << 22) && (u64)scr_stride * 16 < 0x40000000ull;
     if (pc_geo && (!c->dbg.no_pc_auto || c->dbg.use_pc || c->dbg.force_pc) && mode1 && pc_lds(4, 8) <= 160 * 1024
-        && ((full_blocks / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc))
-        pairs = 4, S = 8;  // (A) the chip-filling form: 0.673 against k_encode<1>'s 0.708 ms on the headline workload since the producer
+        && (((NB + 63) / 64) * 2 >= (u32)c->num_cus || c->dbg.force_pc))
+        pairs = 4, S = 8;  // (A) the chip-filling form: 0.66 against k_encode<1>'s 0.71 ms on the headline workload since the producer
                            // loads its inputs 16 bytes at a time (equal before that)
-    else if (pc_geo && !mode1 && pc_lds(2, 4) <= 160 * 1024 && full_blocks >= 32 && !c->dbg.no_pc_auto)
+    else if (pc_geo && !mode1 && pc_lds(2, 4) <= 160 * 1024 && (full_blocks >= 32 || c->dbg.force_pc) && !c->dbg.no_pc_auto)
         pairs = c->dbg.pc_b_pairs, S = 4;                                    // (B) every table entry in LDS, two rounds
-    else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && full_blocks >= 16 && !c->dbg.no_pc_auto
-        && (c->dbg.force_pc || (NB == full_blocks && NB % 16 == 0)))
-        pairs = 1, S = 8;  // (C) short lists.  Only when no block is left over: a second launch for the rest -- even one block -- takes a
-                           // lone wave's whole 0.48 ms behind this one (measured on the 5.65 M-int list: 0.39 + 0.49 ms instead of 0.48)
+    else if (pc_geo && mode1 && enc_waves_all <= 2u * (u32)c->num_cus && (full_blocks >= 16 || c->dbg.force_pc) && !c->dbg.no_pc_auto)
+        pairs = 1, S = 8;  // (C) short lists: the call waits for one wave's state chain, and the consumer's is 20 % shorter.  (Lists of
+                           // fewer than 16 full blocks stay with k_encode<1>, which walks a short block's own steps only.)
     if (pairs && (g.ckpt == 0 || g.ckpt % (4u * S) == 0)) {
-        const u32 wgs = full_blocks / (16 * pairs);
+        const u32 wgs = (NB + 16 * pairs - 1) / (16 * pairs);
         const size_t lds = pc_lds(pairs, S);
         if (pow2) rc = S == 8 ? launch_pc<true, 8>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s)
                               : launch_pc<true, 4>(c, g, NSP, src, ns_entries, rowwords, pairs, wgs, lds, blk, scr_stride, ck_state, ck_off, enc_sizes, enc_gsums, s);

@@ -15,6 +15,8 @@
 // DESIGN.md section 5 describes each kernel and the hardware facts they are built around.
 #pragma once
 
+#include <type_traits>
+
 #include "ansx_dev.h"
 
 #ifdef ANSX_STAMPS  // development: per-phase wall-clock stamps of a few workgroups (printed by ansx_last_encode_stats)
@@ -2206,8 +2208,8 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
 // per symbol instead of 44, no LDS gathers, no input loads.  The tables are u16 RUNNING SUMS, one per symbol plus the
 // frame size (freq = next - current; two adjacent ds_read_u16 as before): half the LDS of the 4-byte entries, which is
 // what makes room for the hand-over buffers (2 x S x 1 KB per pair).  One workgroup barrier per batch; double-buffered.
-// Host-checked: every block of the workgroup is a full block, block_ints % (4 S * 4) == 0 (no tail, no leading
-// remainder), restart interval a multiple of 4 S; the other blocks of the call go to k_encode<1> / k_encode<2>.
+// Host-checked: block_ints % 128 == 0 and <= 2^22, restart interval a multiple of 4 S.  The call's last workgroup may hold
+// blocks that do not exist and the partial last block: see "irregular" in the kernel.
 #define ANSX_PC_S 8  // (steps per batch of the default form; the kernel is a template over it)
 __device__ __forceinline__ void pc_store_short_hi(u32 v, ansx_u32x4 rs, u32 voff)
 {
@@ -2247,6 +2249,7 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
         const u32 r0 = producer ? 8u : 0u;
         const u32 lim = ns_cap < NSP ? ns_cap : NSP;
         for (u32 j = 0; j < 8; j++) {
+            if (wb0 + r0 + j >= g.nblocks) break;  // (the list ends inside this workgroup: no such block, its lanes only idle along)
             const u32* row0 = tab32 + (u64)(wb0 + r0 + j) * NSP;
             lds_u16* c0 = (lds_u16*)(ptab + (r0 + j) * rowwords);
             for (u32 e0 = 0; e0 < lim; e0 += 640) {
@@ -2268,15 +2271,52 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
     __syncthreads();
     const u32 b = wb0 + (lane >> 2), ql = lane & 3u;
     const u32 G = g.block_ints >> 2;   // groups of four per block
-    const u32 NBATCH = G / (u32)S;
+    // A workgroup whose 16 x pairs blocks are not all full blocks of the list (the list's last workgroup: blocks that do not exist, the
+    // partial last block) is IRREGULAR: it runs 32 extra steps in front, and its producers hand over NEUTRAL entries -- frequency M,
+    // base 0, no exception bytes: state and cursor stay as they are (x / M * M + x % M = x; 16 M < 2^36 M: no renormalisation) --
+    // wherever a lane has no symbol at a step.  A block of nbk ints has its nbk / 4 groups in the LAST steps, the nbk % 4 tail
+    // symbols (all on state 0, ans_fold.hpp:257-261) in the steps before them on lane 0, neutral entries before that.
+    const bool irr = (u64)(blockIdx.x + 1) * 16u * pairs * g.block_ints > g.n;  // (workgroup-uniform)
+    const u32 Gtot = G + (irr ? (u32)ANSX_ENC_XB : 0u);  // (a whole super-batch of the producer's input ring: its loops keep their shape)
+    const u32 NBATCH = Gtot / (u32)S;
+    const bool exists = b < g.nblocks;
+    const u32 nbk = exists ? geo_block_n(g, b) : 0u;
+    const u32 Gp = nbk >> 2, rt = nbk & 3u;  // this block's groups and tail symbols
     if (producer) {
         // ---------------------------------------------------------------- producer
         const ansx_map f = g.map;
         const u64 iba = (u64)(uintptr_t)(in + (u64)wb0 * g.block_ints);
+        const u64 ifirst = (u64)wb0 * g.block_ints;
+        const u64 irem = ifirst < g.n ? g.n - ifirst : 0;  // ints of the list from this pair's first block on
+        const u32 inrec = (u32)((irem < 16ull * g.block_ints ? irem : 16ull * g.block_ints) * 4);
         const ansx_u32x4 irs = ansx_u32x4{ (u32)__builtin_amdgcn_readfirstlane((u32)iba),
-            (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(16u * g.block_ints * 4u), 0x00020000u };
+            (u32)__builtin_amdgcn_readfirstlane((u32)(iba >> 32) & 0xFFFFu), (u32)__builtin_amdgcn_readfirstlane(inrec), 0x00020000u };
         const u32 tbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)ptab + 4 * (lane >> 2) * rowwords;
         const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
+        // irregular workgroups: the neutral entry of this lane's block.  A frame of 2^16 does not fit the 16-bit frequency field:
+        // its stand-in has frequency 65535 -- no bytes, no renormalisation either, but the state creeps up by a factor
+        // 1 + 2^-16 per step, so the consumer sets the state back to its initial value at the lane's first live step.
+        const u32 lgm = (exists && irr) ? blk[b].logM : 8u;
+        ansx_u32x4 neutral = ansx_u32x4{ 0u, 0u, 0u, 0u };
+        if (irr) {
+            const u32 Mn = lgm <= 15 ? (1u << lgm) : 65535u;
+            const double Md_ = (double)Mn;
+            const double r0 = __builtin_amdgcn_rcp(Md_);
+            const double rc = __builtin_fma(__builtin_fma(-Md_, r0, 1.0 - 1.8189894035458565e-12), r0, r0);
+            neutral = ansx_u32x4{ f64_lo(rc) & ~3u, f64_hi(rc), Mn, 0u };
+        }
+        const u32* const tailp = in + (u64)(exists ? b : 0) * g.block_ints + 3u * Gp;  // tail symbol at step gi: tailp[gi]
+        // x and the entry of (this lane, the step of group index gi) in an irregular workgroup
+        auto fix_x = [&](u32 x, u32 gi) -> u32 {
+            const bool real = gi < Gp, tail = !real && ql == 0 && gi < Gp + rt;
+            u32 tv = 0;
+            if (__builtin_amdgcn_ballot_w64(tail) != 0) tv = tail ? tailp[gi] : 0u;
+            return real ? x : tv;
+        };
+        auto fix_h = [&](const ansx_u32x4& h, u32 gi) -> ansx_u32x4 {
+            const bool live = gi < Gp || (ql == 0 && gi < Gp + rt);
+            return live ? h : neutral;
+        };
         const u32 c32f = 8u + (u32)__builtin_clz(f.t1);  // POW2 maps: t1 = 2^(f+7); 32 - f
         // one symbol's hand-over entry from its value and the two running sums around its symbol
         auto entry = [&](u32 x, u32 k, u32 sh, u32 cur, u32 nxt) {
@@ -2305,6 +2345,48 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             return tbase + 2 * (__umul24(k, f.D) + (x >> sh));
         };
         u32 pb = 0;  // batch being produced
+        const u32 rtl = ql == 0 ? rt : 0u;  // tail steps of this lane (state 0 takes them all)
+        // the S hand-over entries of batch pb (groups gtop - 1 .. gtop - S) from this lane's inputs.  Irregular workgroups: a lane's
+        // batches are all neutral, then one or two boundary batches, then all live.  Neutral lanes store their entries in the first
+        // batch of either buffer (every lane is neutral in the 32 extra steps) and idle afterwards -- masked off, they cost no issue
+        // slot --, boundary batches (at most two per lane, and only the partial block has any that are not at a batch boundary)
+        // take the per-step form for the whole wave.
+        auto emit = [&](u32 (&x)[S], u32 gtop, u32 hb) {
+            bool act = true;
+            if (irr) {
+                const bool real = gtop <= Gp, neut = gtop - (u32)S >= Gp + rtl;
+                if (__builtin_amdgcn_ballot_w64(!real && !neut) != 0) {
+                    u32 kk[S], shh[S], cur[S], nxt[S];
+#pragma unroll
+                    for (int i = 0; i < S; i++) x[i] = fix_x(x[i], gtop - 1u - (u32)i);
+#pragma unroll
+                    for (int i = 0; i < S; i++) {
+                        const u32 la = fold_of(x[i], kk[i], shh[i]);
+                        cur[i] = *(lds_u16*)(size_t)la;
+                        nxt[i] = *(lds_u16*)(size_t)(la + 2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < S; i++) *(lds_x4*)(size_t)(hb + i * 1024) = fix_h(entry(x[i], kk[i], shh[i], cur[i], nxt[i]), gtop - 1u - (u32)i);
+                    return;
+                }
+                if (pb < 2 && neut) {
+#pragma unroll
+                    for (int i = 0; i < S; i++) *(lds_x4*)(size_t)(hb + i * 1024) = neutral;
+                }
+                act = real;
+            }
+            if (act) {
+                u32 kk[S], shh[S], cur[S], nxt[S];
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    const u32 la = fold_of(x[i], kk[i], shh[i]);
+                    cur[i] = *(lds_u16*)(size_t)la;
+                    nxt[i] = *(lds_u16*)(size_t)(la + 2);
+                }
+#pragma unroll
+                for (int i = 0; i < S; i++) *(lds_x4*)(size_t)(hb + i * 1024) = entry(x[i], kk[i], shh[i], cur[i], nxt[i]);
+            }
+        };
         if constexpr (S == 8) {
             // Inputs as 16-byte loads: the 8 groups of a batch are 128 contiguous bytes of the quad's block, lane l of the quad
             // loads bytes [32 l, 32 l + 32) (a quad reads one whole line per batch instead of eight 16-byte pieces of it through
@@ -2318,32 +2400,24 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             auto request = [&](u32 batch, ansx_u32x4 (&d)[2]) {
                 // groups G - 8 batch - 8 .. G - 8 batch - 1; a batch before the block's first group: an offset in the previous
                 // block or beyond num_records -- never consumed
-                const u32 off = vq + 16u * (G - 8u * batch - 8u);
+                const u32 off = vq + 16u * (Gtot - 8u * batch - 8u);
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d[0]) : "v"(off), "s"(irs) : "memory");
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16" : "=v"(d[1]) : "v"(off), "s"(irs) : "memory");
             };
             request(0, w[0]);
             request(1, w[1]);
             request(2, w[2]);
-            for (u32 sb = 0; sb < G / ANSX_ENC_XB; sb++) {
+            for (u32 sb = 0; sb < Gtot / ANSX_ENC_XB; sb++) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     request(pb + 3, w[(t + 3) % 4]);
                     asm volatile("s_waitcnt vmcnt(6)" : "+v"(w[t][0]), "+v"(w[t][1]) : : "memory");  // three younger requests of two loads
                     *(lds_x4*)(size_t)(sbase + 32 * ql) = w[t][0];
                     *(lds_x4*)(size_t)(sbase + 32 * ql + 16) = w[t][1];
-                    u32 xx[8], kk[8], shh[8], cur[8], nxt[8];
+                    u32 xx[8];
 #pragma unroll
                     for (int i = 0; i < 8; i++) xx[i] = *(__attribute__((address_space(3))) const u32*)(size_t)(sbase + 16 * (7 - i) + 4 * (3 - ql));
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const u32 la = fold_of(xx[i], kk[i], shh[i]);
-                        cur[i] = *(lds_u16*)(size_t)la;
-                        nxt[i] = *(lds_u16*)(size_t)(la + 2);
-                    }
-                    const u32 hb = hbase + (pb & 1u) * (S * 1024);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) *(lds_x4*)(size_t)(hb + i * 1024) = entry(xx[i], kk[i], shh[i], cur[i], nxt[i]);
+                    emit(xx, Gtot - 8u * pb, hbase + (pb & 1u) * (S * 1024));
                     pb++;
                     __syncthreads();
                 }
@@ -2353,7 +2427,7 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
         }
         // byte offset of group (G - 32), this lane's state, in that view; a group before the block's first one gives an offset
         // inside the previous block or beyond num_records (reads 0): never consumed
-        u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (G - ANSX_ENC_XB);
+        u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (Gtot - ANSX_ENC_XB);
         u32 xa[ANSX_ENC_XB];
 #define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
 #pragma unroll
@@ -2363,7 +2437,7 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
         for (int i = 0; i < ANSX_ENC_XB; i += 8)
             asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
                          "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
-        for (u32 sb = 0; sb < G / ANSX_ENC_XB; sb++) {
+        for (u32 sb = 0; sb < Gtot / ANSX_ENC_XB; sb++) {
             const u32 vnext = vcur - 16 * ANSX_ENC_XB;
 #pragma unroll
             for (int t = 0; t < ANSX_ENC_XB / S; t++) {
@@ -2380,16 +2454,10 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
                 static_assert(S == 4 || S == 8, "");
 #pragma unroll
                 for (int i = 0; i < S; i++) asm volatile("" : "+v"(xa[t * S + i]));
-                u32 kk[S], shh[S], cur[S], nxt[S];
+                u32 xs_[S];
 #pragma unroll
-                for (int i = 0; i < S; i++) {
-                    const u32 la = fold_of(xa[t * S + i], kk[i], shh[i]);
-                    cur[i] = *(lds_u16*)(size_t)la;
-                    nxt[i] = *(lds_u16*)(size_t)(la + 2);
-                }
-                const u32 hb = hbase + (pb & 1u) * (S * 1024);
-#pragma unroll
-                for (int i = 0; i < S; i++) *(lds_x4*)(size_t)(hb + i * 1024) = entry(xa[t * S + i], kk[i], shh[i], cur[i], nxt[i]);
+                for (int i = 0; i < S; i++) xs_[i] = xa[t * S + i];
+                emit(xs_, Gtot - (u32)S * pb, hbase + (pb & 1u) * (S * 1024));
                 pb++;
                 __syncthreads();
             }
@@ -2404,11 +2472,12 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
         return;
     }
     // -------------------------------------------------------------------- consumer
-    ansx_blk* B = &blk[b];
+    ansx_blk* B = &blk[exists ? b : 0];
     // a block without a model (an error, an unresolved model, a one-value block of the compaction layer) goes through the
-    // motions with every store out of range and publishes its special size at the end
-    const bool skip = B->status || !B->resolved || B->pa_sigma == 1;
-    const u32 logM = B->logM;
+    // motions with every store out of range and publishes its special size at the end; a block that does not exist (the list
+    // ends inside this workgroup) likewise, and publishes nothing
+    const bool skip = !exists || B->status || !B->resolved || B->pa_sigma == 1;
+    const u32 logM = exists ? B->logM : 8u;
     const u64 Lb = (u64)16 << logM;
     const double Md = (double)(1u << logM);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -2419,7 +2488,7 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
     const u32 obase = (u32)((lane >> 2) * scr_stride);
     u8* out = scratch + (u64)b * scr_stride;
     const u32 cg = g.ckpt >> 2;  // groups per restart interval (0 = none)
-    u32 ck_seg = (cg && G && !skip) ? (G - 1) / cg : 0;  // next restart point to record: segment index
+    u32 ck_seg = (cg && Gp && !skip) ? (Gp - 1) / cg : 0;  // next restart point to record: segment index (of THIS block's groups)
     u32 ck_g = ck_seg * cg;                               // ... and its group index
     const u32 pbias = obase;
     double sd = (double)Lb;
@@ -2453,10 +2522,11 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
     };
     const u32 hbase = (u32)(uintptr_t)(__attribute__((address_space(3))) const u32*)hand + 16 * lane;
     const u32 four_pos = 4u << (8 * ql), lomask = (1u << (8 * ql)) - 1u, ql8 = 8 * ql;
-    u32 gi = G;
-    for (u32 cb = 0; cb < NBATCH; cb++) {
-        __syncthreads();
-        const u32 hb = hbase + (cb & 1u) * (S * 1024);
+    u32 gi = Gtot;  // groups the steps still to come could hold (an irregular workgroup's first 32 are neutral for every full block)
+    const u32 gstart = Gp + (ql == 0 ? rt : 0u);  // irregular: this lane's first live step is the one of group index gstart - 1
+    const double sd_first = sd;
+    const bool creeps = irr && logM == 16;  // (this lane's neutral steps are the stand-in: see the producer)
+    auto steps = [&](auto RESET, u32 hb) {
         ansx_u32x4 h[S];
 #pragma unroll
         for (int i = 0; i < S; i++) h[i] = *(lds_x4*)(size_t)(hb + i * 1024);
@@ -2472,6 +2542,7 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             const u32 off1 = (h[i].x << 31) + ANSX_BUF_OOB;  // 0 when k is odd
             const u32 off2 = (k - 2u) & 0x80000001u;          // k & 1 when k >= 2
             // state chain (enc_update_n / the scheduled loop of k_encode)
+            if constexpr (decltype(RESET)::value) sd = gi - (u32)i == gstart ? sd_first : sd;  // (the neutral steps before it have moved the state)
             const bool rn = f64_hi(sd) >= thr_hi;
             const u32 w = f64_lo(sd + 4503599627370496.0);
             int ex = rn ? -32 : 0;
@@ -2495,9 +2566,17 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             asm volatile("" :: "v"(a + off1), "v"(a + off2), "v"(rn ? a + k : ANSX_BUF_OOB), "v"(w));
 #endif
         }
+    };
+    for (u32 cb = 0; cb < NBATCH; cb++) {
+        __syncthreads();
+        const u32 hb = hbase + (cb & 1u) * (S * 1024);
+        // (the batch with a creeping lane's first live step -- one or two per irregular workgroup -- runs the form that sets the state back)
+        if (irr && __builtin_amdgcn_ballot_w64(creeps && gstart <= gi && gstart + (u32)S > gi) != 0) steps(std::true_type{}, hb);
+        else steps(std::false_type{}, hb);
         gi -= (u32)S;
         record(gi);
     }
+    if (!exists) return;
     if (skip) {
         if (ql == 0) {
             const u32 sz = (B->pa_sigma == 1 && !B->status) ? B->pre_bytes : 0u;

@@ -962,8 +962,7 @@ def test_encoder_table_modes(A, ctx):
 
 def test_encoder_producer_consumer_pairs(A):
     """k_encode_pc (round 4): the LDS-table encoder as a producer wave (fold map, table look-up, reciprocal; a batch ahead,
-    16 bytes per symbol through LDS) and a consumer wave (state chain, byte emission) per 16 blocks, over the leading
-    workgroups of 64 full blocks; the remaining blocks go to k_encode<1>.  Forced on small lists here (the launch site
+    16 bytes per symbol through LDS) and a consumer wave (state chain, byte emission) per 16 blocks.  Forced on small lists here (the launch site
     keeps it for grids that fill the chip).  Every block stream, restart point and header field must equal the oracle's,
     the container must equal the one the single-wave kernel writes, on the first call of a geometry (discovery path) and on
     the hinted ones."""
@@ -1002,9 +1001,9 @@ def test_encoder_producer_consumer_pairs(A):
         c_pc.close()
     # the two shapes the launch site chooses by itself: (C) short lists -- one pair per workgroup -- and (B) alphabets too
     # large for 64 LDS tables per CU whose tables fit at 32 (two pairs per workgroup, batches of 4 steps; BASELINE config 3)
-    auto = [("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3),                    # C: three workgroups (chosen only when no block is left over)
+    auto = [("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3),                    # C: three workgroups
             ("uniform256", ol.MSB, 0, 512, 0, 16 * 512),                           # C: one workgroup, no restart points
-            ("zipf24", ol.FOLD, 3, 1024, 256, 32 * 1024 * 2 + 1024 * 3 + 9),        # B: two workgroups + rest through k_encode<2>
+            ("zipf24", ol.FOLD, 3, 1024, 256, 32 * 1024 * 2 + 1024 * 3 + 9),        # B: three workgroups, the last one 3 blocks + 9 ints
             ("zipf24", ol.RFOLD, 3, 2048, 512, 32 * 2048),                         # B: exactly one workgroup
             ("uniform24", ol.FOLD, 3, 1024, 16, 32 * 1024 + 1024)]                 # B: a restart point every 4 groups (one batch)
     for fam, kind, f, block, ck, n in auto:
@@ -1026,6 +1025,55 @@ def test_encoder_producer_consumer_pairs(A):
         check_container(A, got, data, kind, f, block, ck)
         assert np.array_equal(codec.decode(got, n), data)
         c_pc.close()
+
+
+def test_encoder_pairs_take_ragged_lists_whole(A):
+    """k_encode_pc takes every block of a call: its last workgroup pads itself with neutral steps where the list ends inside it
+    (blocks that do not exist; the partial last block, whose n % 4 tail symbols go to state 0 before its groups).  A frame of
+    2^16 has no neutral entry in the 16-bit frequency field: its stand-in lets the state creep and the consumer sets it back
+    at the lane's first live step -- so one case must have a partial block with such a frame.  No second encoder launch."""
+    cases = [  # (family, kind, f, block_ints, ckpt, n, forced)
+        ("geom0.01", ol.FOLD, 1, 512, 128, 512 * 5 + 130, True),               # one workgroup: 5 blocks + 130 ints (tail 2), 58 that are not there
+        ("uniform20", ol.FOLD, 1, 1024, 256, 64 * 1024 + 1024 * 17 + 1023, True),  # tail 3
+        ("zipf20s1.2", ol.FOLD, 1, 1024, 256, 64 * 1024 * 2 + 1, True),          # a one-int last block
+        ("zipf20s1.2", ol.RFOLD, 1, 1024, 128, 64 * 1024 + 517, True),
+        ("zipf20s1.2", ol.MSB, 0, 2048, 512, 64 * 2048 + 2048 * 63 + 2047, True),
+        ("uniform24", ol.FOLD, 3, 1024, 256, 32 * 1024 * 2 + 1024 * 5 + 1001, False),  # shape B (two pairs, S = 4), frames of 2^16
+        ("uniform24", ol.FOLD, 3, 2048, 64, 32 * 2048 + 2048 * 31 + 6, False),
+        ("zipf20s1.2", ol.FOLD, 1, 1024, 256, 16 * 1024 * 3 + 1024 * 2 + 333, False),  # shape C (one pair)
+        ("const7", ol.FOLD, 1, 1024, 256, 64 * 1024 + 700, True),                # frame 32768: the largest with a true neutral entry
+        ("uniform24", ol.FOLD, 3, 1 << 19, 4096, (1 << 19) * 2 + 500001, True),  # frames of 2^16, the partial block's too
+    ]
+    saw_wide_partial = False
+    for fam, kind, f, block, ck, n, forced in cases:
+        if fam == "const7":
+            data = np.full(n, 7, dtype=np.uint32)
+        else:
+            data = ol.gen_inputs(fam, n, seed=131 + f + block)
+        if kind == ol.RFOLD:
+            data = np.minimum(data, np.uint32((1 << 30) - 1 - (1 << (f + 7))))
+        last = data[(n // block) * block:]
+        if len(last) and kind == ol.FOLD and ol.oracle_encode(kind, f, last)[1].log2_frame == 16:
+            saw_wide_partial = True
+        kw = dict(block_ints=block, ckpt_interval=ck)
+        c_ref = A.Context(0)
+        c_ref.debug_set("ANSX_NO_PC", "1")
+        ref = codec_for(A, c_ref, kind, f, **kw).encode(data)
+        c_ref.close()
+        c_pc = A.Context(0)
+        if forced:
+            c_pc.debug_set("ANSX_FORCE_PC", "1")
+        c_pc.profile(True)
+        codec = codec_for(A, c_pc, kind, f, **kw)
+        for call in range(3):
+            got = codec.encode(data)
+            assert c_pc.last_encode_stats()["path"] & 128, (fam, kind, f, block, ck, n, call)
+            assert np.array_equal(got, ref), (fam, kind, f, block, ck, n, call)
+            assert "k_encode_rest" not in [k for k, _, _ in c_pc.profile_get()], (fam, n)
+        check_container(A, got, data, kind, f, block, ck)
+        assert np.array_equal(codec.decode(got, n), data)
+        c_pc.close()
+    assert saw_wide_partial
 
 
 def test_prelude_parser_paths(A, ctx):

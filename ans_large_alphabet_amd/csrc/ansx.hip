@@ -25,6 +25,7 @@
 #include "ansx_fastmodel.h"
 #include "ansx_gen.h"
 #include "ansx_pa.h"
+#include "ansx_intsparse.h"
 
 namespace {
 
@@ -76,6 +77,8 @@ struct ansx_ctx {
     u32 cur_nt = 0;              // set by encode_dev: candidates per block for the fast model path of this call (0 = exact path)
     u32 cur_rf_slots = 0;        // set by encode_dev for the optimistic attempt of the current call
     u32 cur_pa_distinct = 0;     // the same for the compaction layer's k_pa_remap (the hint itself)
+    std::set<u64> int_sparse_hint;  // plain-ANSint geometries whose values outgrew the dense 16384-symbol model: rank space from the start
+    bool cur_int_sparse = false;    // this call models its blocks in rank space (ansx_intsparse.h)
     ansx_encode_stats last = {};
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
@@ -567,12 +570,24 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         } else {
             HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
             LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, pa_slots, pa_uqcap, (u32*)c->mapped.p,
-                (u32*)c->pa_alpha.p, blk, gflags, 1u << 30);
+                (u32*)c->pa_alpha.p, blk, gflags, 1u << 30, 0u);
         }
         const size_t lds2 = pa_small ? ((size_t)3 * pa_uqcap + 32) * 4 : ((size_t)2 * ANSX_PA_MAX_BLOCK + 16) * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_header, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         LAUNCH(c, "k_pa_header", k_pa_header, NB, 256, lds2, s, g, (const u32*)c->pa_alpha.p, blk, (u8*)c->scratch.p,
             (u64)scr_stride, pa_small ? pa_uqcap : (u32)ANSX_PA_MAX_BLOCK);
+        src = (const u32*)c->mapped.p;
+    }
+    const bool sparse = c->cur_int_sparse;
+    if (sparse) {
+        // plain ANSint on values beyond the dense model (ansx_intsparse.h): the codec runs on every block's 0-based ranks
+        if (g.block_ints > ANSX_PA_MAX_BLOCK) return ANSX_ERR_DOMAIN;  // (the per-block remap holds a block in one CU's LDS)
+        if ((rc = ensure(c, c->mapped, (size_t)NB * g.block_ints * 4))) return rc;
+        if ((rc = ensure(c, c->pa_alpha, (size_t)NB * g.block_ints * 4))) return rc;
+        const size_t lds1 = ((size_t)ANSX_PA_SLOTS + ANSX_PA_MAX_BLOCK) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_pa_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        LAUNCH(c, "k_pa_remap", k_pa_remap, NB, 1024, lds1, s, d_in, g, (u32)ANSX_PA_SLOTS, (u32)ANSX_PA_MAX_BLOCK, (u32*)c->mapped.p,
+            (u32*)c->pa_alpha.p, blk, gflags, (u32)ANSX_SP_VALUE_LIMIT, 1u);
         src = (const u32*)c->mapped.p;
     }
     c->cur_src = src;
@@ -754,6 +769,12 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         LAUNCH(c, "k_write_prelude", (k_write_prelude<16>), NB, 256, (size_t)pre_cap * 12 + 64, s, g, NSP,
             (const ansx_enc_entry*)c->table.p, (const u32*)c->tab32.p, hist, blk, (u8*)c->scratch.p,
             (u64)scr_stride, mostfreq, hints, pre_cap, geo);
+    } else if (sparse) {
+        // the reference's prelude over the VALUE range, from the rank-space model (16-byte entries: always16) and the block's values
+        const size_t sp_lds = (size_t)(2 * ANSX_SP_MAX_SIGMA + 2) * 4;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_int_sparse_prelude, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
+        LAUNCH(c, "k_int_sparse_prelude", k_int_sparse_prelude, NB, 256, sp_lds, s, g, NSP, (const u32*)c->pa_alpha.p,
+            (const ansx_enc_entry*)c->table.p, blk, (u8*)c->scratch.p, (u64)scr_stride, (u32)ANSX_SP_MAX_SIGMA, (u32)(4 * NSP), gflags);
     } else {
         const size_t gen_lds = (size_t)pre_cap * 8 + 64;  // (as long as the call's largest alphabet, not as its slot count: workgroups per CU)
         if (gen_lds > 150 * 1024) {  // f = 6, 7: the writer's two arrays in HBM
@@ -1086,6 +1107,8 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
     const u64 key = ((u64)P.g.pa << 48) | ((u64)P.g.kind << 40) | ((u64)P.g.f << 32) | P.g.block_ints;
     u32 seen = 0;
     int rc = ANSX_RETRY_GENERAL;
+    const bool int_plain = P.g.kind == ANSX_INT && !P.g.pa;
+    c->cur_int_sparse = int_plain && c->int_sparse_hint.count(key) != 0 && P.g.block_ints <= ANSX_PA_MAX_BLOCK;
     const auto it = c->ns_hint.find(key);
     const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
     const bool eligible = !P.plain && hint != 0 && (P.NSP <= 4096 || (P.NSP <= 16384 && P.g.kind != ANSX_INT && !P.g.pa)) && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
@@ -1118,6 +1141,19 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
         path = eligible ? path | 16u : 0u;
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
+    // Plain ANSint: the dense model takes values below 16384; a call with larger ones is repeated in rank space, and so is
+    // every later call of the geometry from the start -- unless its values turn out small, where the dense form (whose
+    // containers carry parse hints) is the one a fresh context would have written: equal inputs, equal bytes.
+    if (int_plain && !c->cur_int_sparse && rc == ANSX_ERR_DOMAIN && P.g.block_ints <= ANSX_PA_MAX_BLOCK) {
+        c->cur_int_sparse = true;
+        c->int_sparse_hint.insert(key);
+        rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
+    } else if (int_plain && c->cur_int_sparse && rc == ANSX_OK && c->h_pin[ANSX_G_VMAX] < P.NSP) {
+        c->cur_int_sparse = false;
+        c->int_sparse_hint.erase(key);
+        rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
+    }
+    if (c->cur_int_sparse) path |= 256u;  // plain ANSint modelled in rank space
     if (rc == ANSX_RETRY_WIDE) return rc;
     // close calls of the stop rule (counted by the exact kernels only; the fast path repeats on them): the host decides
     u32 redecided = 0;
@@ -1186,7 +1222,8 @@ int encode_dev(ansx_ctx* c, const Plan& P0, const u32* d_in, u8* d_out, size_t c
 template <bool RF>
 int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const u64* boff,
     const u64* ck_state, const u32* ck_off, u64 payload_off, u32* d_out, u32 maxM, u32 max_ns,
-    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info, const u32* hints, u32 max_ep)
+    u32 max_block_bytes, u64 cont_bytes, u32* gflags, hipStream_t s, const uint4* pa_info, const u32* hints, u32 max_ep,
+    bool parsed = false)
 {
     // max_ep: the header's bound on the symbols PRESENT in a block (<= max_ns, its bound on their indices): the
     // rank / select decoder keeps one 8-byte entry per present symbol, so this -- not max_ns -- sizes its LDS
@@ -1204,7 +1241,9 @@ int launch_decode(ansx_ctx* c, const ansx_geo& g, u32 NSP, const u8* cont, const
     u32 stage_words = ANSX_PF_SW;
     if (c->dbg.parse_stage_words >= 2 && c->dbg.parse_stage_words <= ANSX_PF_SW)  // tests: force the fast loop's in-kernel fallback
         stage_words = c->dbg.parse_stage_words & ~1u;
-    if (c->dbg.parse_generic) {
+    if (parsed) {
+        // (plain ANSint: k_int_sparse_parse has filled dec_cum / dec_info in rank space)
+    } else if (c->dbg.parse_generic) {
         LAUNCH(c, "k_parse_prelude", (k_parse_prelude<RF>), (g.nblocks + 63) / 64, 64, 0, s, cont, g, NSP,
             boff, payload_off, max_ns, maxM, (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, gflags, pa_info);
     } else if (hints != nullptr && !c->dbg.parse_win && !c->dbg.parse_fast) {
@@ -1461,9 +1500,10 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
             sh += 7;
         }
         u32 lg = hp[pos];
-        if (ms >= P.NSP || lg > 31) return ANSX_ERR_FORMAT;
+        const bool int_sp = P.g.kind == ANSX_INT && !P.g.pa;  // (any max_sym below 2^30: the model is parsed in rank space)
+        if ((int_sp ? ms >= ANSX_SP_VALUE_LIMIT : ms >= P.NSP) || lg > 31) return ANSX_ERR_FORMAT;
         maxM = 1u << lg;
-        max_ns = ms + 1;
+        max_ns = ms + 1 < P.NSP ? ms + 1 : P.NSP;
         // (the two index entries of the one block go up from pinned memory: no wait -- the page is next written by
         // this call's final read-back, which the stream orders behind this copy)
         u64* hb = (u64*)((u8*)c->h_pin + 64 + 32);
@@ -1556,17 +1596,30 @@ int decode_dev(ansx_ctx* c, const Plan& Pin, const u8* d_in, size_t in_bytes, u3
             (u32*)c->pa_alpha.p, (uint4*)c->pa_info.p, gflags);
         pa_info = (const uint4*)c->pa_info.p;
     }
+    const bool int_sparse = P.g.kind == ANSX_INT && !P.g.pa;
+    if (int_sparse) {
+        // plain ANSint: the prelude ranges over the VALUES (any max_sym); its present symbols become the block's ranks
+        // (ansx_intsparse.h) -- whichever model the encoder ran, the stream is the reference's
+        if ((rc = ensure(c, c->pa_alpha, (size_t)P.g.nblocks * P.g.block_ints * 4))) return rc;
+        if ((rc = ensure(c, c->pa_info, (size_t)P.g.nblocks * 16))) return rc;
+        if ((rc = ensure(c, c->dec_cum, (size_t)P.g.nblocks * (P.NSP + 8) * 4))) return rc;
+        if ((rc = ensure(c, c->dec_info, (size_t)P.g.nblocks * 16))) return rc;
+        LAUNCH(c, "k_parse_prelude", k_int_sparse_parse, (P.g.nblocks + 63) / 64, 64, 0, s, cont, P.g, P.NSP, boff, payload_off, maxM,
+            (u32*)c->dec_cum.p, (uint4*)c->dec_info.p, (u32*)c->pa_alpha.p, (uint4*)c->pa_info.p, gflags);
+    }
     if (P.g.kind == ANSX_RFOLD)
         rc = launch_decode<true>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
             max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints, max_ep ? max_ep : max_ns);
     else
         rc = launch_decode<false>(c, P.g, P.NSP, cont, boff, ck_state, ck_off, payload_off, d_out, maxM,
-            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints, max_ep ? max_ep : max_ns);
+            max_ns, max_block_bytes, (u64)payload_off + in_bytes_payload, gflags, s, pa_info, hints, max_ep ? max_ep : max_ns, int_sparse);
     if (rc) return rc;
+    if (int_sparse)
+        LAUNCH(c, "k_int_unmap", k_int_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, (const uint4*)c->pa_info.p, d_out, gflags);
     if (P.g.pa)
         LAUNCH(c, "k_pa_unmap", k_pa_unmap, P.g.nblocks, 256, 0, s, P.g, (const u32*)c->pa_alpha.p, pa_info, d_out, gflags);
     if (spec) LAUNCH(c, "k_check_header", k_check_header, 1, 64, 0, s, d_in, Hspec, gflags);
-    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin, c->misc.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (spec && (c->h_pin[ANSX_G_ERR] & (1u << ANSX_G_HDR_BIT))) {
         c->hdr_cache.erase(hkey);

@@ -52,7 +52,8 @@ struct ansx_blk {
     // per-block alphabet compaction (ansx_pa.h, src/pseudo_adaptive.cpp:85-130)
     u32 pre_bytes;      // bytes of the alphabet header in front of the codec stream (0 without compaction)
     u32 pa_sigma;       // distinct values of the block (0 without compaction; 1: the block has no codec stream)
-    u32 pad_[2];
+    u32 sp_sigma;       // plain ANSint modelled in rank space (ansx_intsparse.h): distinct values of the block, else 0
+    u32 pad_[1];
 };
 
 // encoder table entry (ans_fold.hpp:30-34 enc_entry_fold, plus the reciprocal used for the
@@ -71,7 +72,8 @@ enum { ANSX_G_MAXLOGM = 0, ANSX_G_MAXNSYMS = 1, ANSX_G_ERR = 2, ANSX_G_PAD = 3,
     ANSX_G_NEAR = 6,    // stop-rule comparisons XH < 1.001 H closer than 1e-12 relative (see ansx_near_threshold)
     ANSX_G_RFDIST = 7,  // rfold: the most distinct values any block of the call had (sizes the next call's hash tables)
     ANSX_G_MAXT = 8,    // largest chosen candidate index t (frame = M0 * 2^t) of the call: lanes per block of k_candidates
-    ANSX_G_MAXSIGMA = 9 };  // most symbols PRESENT in any block (<= its alphabet size): goes into the container header and
+    ANSX_G_MAXSIGMA = 9,
+    ANSX_G_VMAX = 10 };  // plain ANSint in rank space: the call's largest value (decides whether the dense model applies)  // most symbols PRESENT in any block (<= its alphabet size): goes into the container header and
                             // sizes the decoder's per-present-symbol table
 
 // The one step of the path whose parity with the reference is empirical rather than by construction:

@@ -33,8 +33,11 @@ __device__ __forceinline__ u32 pa_slot(u32 v, u32 slots) { return (u32)(((u64)(v
 // repeated with the full sizes).
 __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const ansx_geo& g, u32 slots, u32 uqcap,
     u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags,
-    u32 value_limit)
+    u32 value_limit, u32 mode = 0)
 {
+    // mode 1 (plain ANSint in rank space, ansx_intsparse.h): alpha_sum receives the distinct VALUES (not their running
+    // sums: no 32-bit sum to overflow), ranks are 0-based, the count goes to blk[].sp_sigma -- a one-value block keeps its
+    // codec stream -- and the call's largest value to gflags[ANSX_G_VMAX].  Always run with the full table sizes.
     extern __shared__ u32 pa_lds[];
     __shared__ u32 sh_cnt, sh_max, sh_ovf;
     __shared__ u64 sh_part64[20];
@@ -93,6 +96,7 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
     const u32 sigma = sh_cnt;
     if (tid == 0 && sh_max >= value_limit) atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
     if (tid == 0 && sigma > gflags[ANSX_G_RFDIST]) atomicMax(&gflags[ANSX_G_RFDIST], sigma);
+    if (mode == 1 && tid == 0 && sh_max > gflags[ANSX_G_VMAX]) atomicMax(&gflags[ANSX_G_VMAX], sh_max);
     // sort the distinct values (bitonic, padded to a power of two).  Every thread keeps E = N2 / 1024 consecutive
     // elements in registers: a stage whose partner distance is below E is a compare-exchange inside the thread, below
     // 64 E a shuffle inside the wave, and only the others (10 of the 78 stages at N2 = 4096) go through LDS and a
@@ -155,6 +159,11 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
     case 8: sort_regs(std::integral_constant<u32, 8>{}); break;
     default: sort_regs(std::integral_constant<u32, 16>{}); break;
     }
+    if (mode == 1) {
+        u32* as = alpha_sum + (u64)b * g.block_ints;
+        for (u32 j = tid; j < sigma; j += nt) as[j] = uq[j];
+        if (tid == 0) blk[b].sp_sigma = sigma;
+    } else
     // running sums of the alphabet (pseudo_adaptive.cpp:103-105, u32 there: the exact sum must fit)
     {
         const u32 per = (sigma + nt - 1) / nt;
@@ -189,14 +198,15 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
         }
 #pragma unroll
         for (u32 q = 0; q < PA_VPT; q++)
-            if (tid + q * nt < nb) dst[tid + q * nt] = lo[q] + 1;
+            if (tid + q * nt < nb) dst[tid + q * nt] = lo[q] + (mode == 1 ? 0u : 1u);
     }
 }
 
 __global__ __launch_bounds__(1024) void k_pa_remap(const u32* __restrict__ in, ansx_geo g, u32 slots, u32 uqcap,
-    u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit)
+    u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk, u32* __restrict__ gflags, u32 value_limit,
+    u32 mode)
 {
-    pa_remap_body(in, g, slots, uqcap, mapped, alpha_sum, blk, gflags, value_limit);
+    pa_remap_body(in, g, slots, uqcap, mapped, alpha_sum, blk, gflags, value_limit, mode);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_pa_remap2(const u32* __restrict__ in,
     ansx_geo g, u32 slots, u32 uqcap, u32* __restrict__ mapped, u32* __restrict__ alpha_sum, ansx_blk* __restrict__ blk,

@@ -446,19 +446,29 @@ size_t ans_oracle_bound(int kind, uint32_t f, size_t n)
     return hdr + 8 + 4 * nsyms_max + 8 + 7 * n + 32;
 }
 
+/* ANSint on values beyond that range (the GPU path models them in rank space, ansx_intsparse.h; the restatement stays the
+ * reference's dense one): the prelude codes max_value + 1 items, of which only nodes with a present symbol in reach carry
+ * bits -- at most 62 nodes of at most 31 bits per distinct value. */
+size_t ans_oracle_bound_int(size_t n, uint32_t max_value)
+{
+    size_t b = ans_oracle_bound(ANS_ORACLE_INT, 1, n);
+    if (max_value >= 16384 && (size_t)max_value > n + 1024) b += 256 * n + 64;
+    return b;
+}
+
 size_t ans_oracle_encode(int kind, uint32_t f, const uint32_t* in, size_t n, uint8_t* out,
     size_t cap, ans_oracle_info* info, size_t ckpt_interval, uint64_t* ckpt_states,
     uint32_t* ckpt_off, size_t* n_ckpt)
 {
     if (kind == ANS_ORACLE_MSB || kind == ANS_ORACLE_INT) f = 1; /* fidelity is not a parameter of ANSmsb / ANSint */
     if (n == 0 || f < 1 || f > 7) return 0; /* n == 0 never terminates in the reference (F4) */
-    if (cap < ans_oracle_bound(kind, f, n)) return 0;
     uint32_t int_max = 0; /* ANSint (ans_int.hpp:40-48): symbols are the values, alphabet = max value + 1 */
     if (kind == ANS_ORACLE_INT) {
         for (size_t i = 0; i < n; i++)
             if (in[i] > int_max) int_max = in[i];
-        if ((size_t)int_max > n + 1024 && int_max >= 16384) return 0; /* outside this oracle's range, see ans_oracle_bound */
-    }
+        if (int_max >= (1u << 30)) return 0; /* the code's universe M + max + 2 is kept below 2^31 */
+        if (cap < ans_oracle_bound_int(n, int_max)) return 0;
+    } else if (cap < ans_oracle_bound(kind, f, n)) return 0;
     const uint32_t T = kind == ANS_ORACLE_INT ? 0xFFFFFFFFu : fold_T(f); /* ANSint never strips bytes */
     const uint32_t MAX_SIGMA = kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : (kind == ANS_ORACLE_INT ? int_max + 1 : fold_max_sigma(f));
     ans_oracle_info local;
@@ -690,7 +700,7 @@ int ans_oracle_decode(int kind, uint32_t f, const uint8_t* in, size_t nbytes_in,
     }
     uint32_t max_sym_peek; /* guard against corrupt input: the alphabet has < 2^(f+9) symbols */
     vbyte_get(p, &max_sym_peek);
-    if (kind == ANS_ORACLE_INT ? ((size_t)max_sym_peek > n + 1024 && max_sym_peek >= 16384)
+    if (kind == ANS_ORACLE_INT ? (max_sym_peek >= (1u << 30))
                                : max_sym_peek >= (kind == ANS_ORACLE_MSB ? MSB_MAX_SIGMA : fold_max_sigma(f)))
         return -2;
     uint32_t* nfreqs = (uint32_t*)calloc((size_t)max_sym_peek + 2, sizeof(uint32_t));

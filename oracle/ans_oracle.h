@@ -105,6 +105,8 @@ void ans_oracle_hash_spans(const uint8_t* buf, const uint64_t* offs, size_t nspa
 
 /* Worst-case stream size for one encode() call. */
 size_t ans_oracle_bound(int kind, uint32_t f, size_t n);
+/* ... of ANSint (kind 3) when the list's largest value is known (any value below 2^30) */
+size_t ans_oracle_bound_int(size_t n, uint32_t max_value);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,29 @@ def main():
         json.dump(rows, fh, indent=0)
     assert sum(1 for r in rows if r["log2_frame"] > 16) >= 2
     print("ansint.json:", len(rows), "entries; frames", sorted(set(r["log2_frame"] for r in rows)))
+    # ansint_large.json (round 4): values far beyond 16384 -- the reference sizes its model by the largest value
+    # (ans_int.hpp:41-51) and its prelude codes max_sym + 1 items; the GPU path models such a list in rank space
+    # (csrc/ansx_intsparse.h) and must write the same bytes.  Lists of at most 16384 ints (one block's worth).
+    big = []
+    for shape in ("uniform", "skew", "cluster"):
+        for n in (7, 1000, 5000, 16384):
+            for lg in (17, 20, 22):
+                seed = 4000 + n % 89 + lg
+                d = ol.ansint_large_list(n, 1 << lg, seed, shape)
+                raw = ol.ref_encode(ol.INT, 0, d)
+                s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+                assert raw.size == s.size and np.array_equal(ol.ref_decode(ol.INT, 0, raw, n), d)
+                assert np.array_equal(ol.canonicalize(raw, info), ol.canonicalize(s, info))
+                row = {"shape": shape, "n": n, "log2_vmax": lg, "seed": seed, "log2_frame": int(info.log2_frame),
+                       "prelude_bytes": int(info.prelude_bytes), "stream_len": int(raw.size),
+                       "input_sha256": hashlib.sha256(d.tobytes()).hexdigest(),
+                       "stream_sha256": hashlib.sha256(ol.canonicalize(raw, info).tobytes()).hexdigest()}
+                if n <= 1000:
+                    row["stream_hex"] = ol.canonicalize(raw, info).tobytes().hex()
+                big.append(row)
+    with open(os.path.join(HERE, "ansint_large.json"), "w") as fh:
+        json.dump(big, fh, indent=0)
+    print("ansint_large.json:", len(big), "entries; preludes", min(r["prelude_bytes"] for r in big), "..", max(r["prelude_bytes"] for r in big), "bytes")
 
 
 if __name__ == "__main__":

@@ -80,6 +80,8 @@ def _load_oracle():
     lib.ans_oracle_prelude_hints.argtypes = [_u8p, _u32p]
     lib.ans_oracle_bound.restype = C.c_size_t
     lib.ans_oracle_bound.argtypes = [C.c_int, C.c_uint32, C.c_size_t]
+    lib.ans_oracle_bound_int.restype = C.c_size_t
+    lib.ans_oracle_bound_int.argtypes = [C.c_size_t, C.c_uint32]
     lib.ans_oracle_blocks_digest.restype = C.c_int
     lib.ans_oracle_blocks_digest.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _u32p, _u64p, _u64p,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -203,11 +205,34 @@ def ref_bwtmtf(T, n):
     return out[:m].copy()
 
 
+def ansint_large_list(n, vmax, seed, shape):
+    """Lists for plain ANSint whose values go far beyond the dense 16384-symbol model (tests/golden/ansint_large.json)."""
+    rng = np.random.default_rng(seed)
+    if shape == "uniform":
+        d = rng.integers(0, vmax, n)
+    elif shape == "skew":  # half the list from 50 small values
+        d = rng.integers(0, vmax, n)
+        d[: n // 2] = rng.integers(0, 50, n // 2)
+        rng.shuffle(d)
+    else:  # "cluster": eight runs of 300 consecutive values
+        base = rng.integers(0, vmax - 300, 8)
+        d = base[rng.integers(0, 8, n)] + rng.integers(0, 300, n)
+    d[int(rng.integers(0, n))] = vmax - 1
+    return d.astype(np.uint32)
+
+
+def stream_bound(kind, f, data):
+    """Worst-case bytes of one stream (ANSint: from the list's largest value, any value below 2^30)."""
+    if kind == INT and data.size:
+        return oracle().ans_oracle_bound_int(data.size, int(data.max()))
+    return oracle().ans_oracle_bound(kind, f, data.size)
+
+
 def oracle_encode(kind, f, data, ckpt_interval=0):
     """Returns (stream bytes as np.uint8, OracleInfo, ckpt_states[nck,4] u64, ckpt_off[nck] u32)."""
     data = np.ascontiguousarray(data, dtype=np.uint32)
     n = data.size
-    cap = oracle().ans_oracle_bound(kind, f, n)
+    cap = stream_bound(kind, f, data)
     out = np.zeros(cap, dtype=np.uint8)
     info = OracleInfo()
     nck_max = (n // ckpt_interval + 1) if ckpt_interval else 1
@@ -298,7 +323,7 @@ def canonicalize_pa(stream, pinfo, info):
 def ref_encode(kind, f, data, lib="libans_ref.so"):
     data = np.ascontiguousarray(data, dtype=np.uint32)
     n = data.size
-    cap = oracle().ans_oracle_bound(kind, f, n) + 64
+    cap = stream_bound(kind, f, data) + 64
     out = np.zeros(cap, dtype=np.uint8)
     nb = ref(lib).ref_encode(kind, f, data, n, out, cap)
     return out[:nb].copy()

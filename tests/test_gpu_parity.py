@@ -92,6 +92,9 @@ def check_container(A, cont, data, kind, f, block, ckpt):
         assert np.array_equal(parts["ckpt_state"][b][:nck], st), b
         max_lg = max(max_lg, info.log2_frame)
         max_ns = max(max_ns, info.max_sym + 1)
+    if kind == ol.INT and not (H.kind & 0x100) and int(data.max()) >= 16384:
+        # plain ANSint beyond the dense model: modelled in rank space, the header bounds the ranks (distinct values per block)
+        max_ns = max(np.unique(data[b * block:(b + 1) * block]).size for b in range(nblocks))
     assert H.max_log2_frame == max_lg and H.max_nsyms == max_ns
     return parts
 
@@ -1562,10 +1565,77 @@ def test_plain_ansint_is_a_drop_in(A, ctx):
         cont = codec.encode(d)
         check_container(A, cont, d, ol.INT, 0, 16384, 1024)
         assert np.array_equal(codec.decode(cont, n), d)
-    # values the 16384-symbol model cannot hold: refused, not mis-coded
+
+
+def test_plain_ansint_beyond_the_dense_model(A):
+    """ANSint sizes its model by the list's largest value (ans_int.hpp:41-51).  Values from 16384 on are modelled in rank
+    space per block (csrc/ansx_intsparse.h) and only the prelude ranges over the values: single-stream bytes equal the
+    reference's (tests/golden/ansint_large.json, made by oracle/_ref: max values 2^17, 2^20, 2^22), reference-made streams
+    decode, every block of a container is the oracle's stream, and the bytes do not depend on what the context encoded
+    before.  What stays out of reach is refused, not mis-coded: blocks longer than 16384 ints with such values."""
+    with open(os.path.join(GOLD, "ansint_large.json")) as fh:
+        gold = json.load(fh)
+    ctx = A.Context(0)
+    for e in gold:
+        d = ol.ansint_large_list(e["n"], 1 << e["log2_vmax"], e["seed"], e["shape"])
+        tag = (e["shape"], e["n"], e["log2_vmax"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == e["input_sha256"], tag
+        codec = A.ANSint(ctx=ctx, block_ints=A.SINGLE_STREAM, compact=False)
+        stream = codec.encode(d)
+        assert ctx.last_encode_stats()["path"] & 256, tag  # the rank-space model ran
+        assert stream.size == e["stream_len"], tag
+        assert hashlib.sha256(stream.tobytes()).hexdigest() == e["stream_sha256"], tag
+        if "stream_hex" in e:
+            assert stream.tobytes().hex() == e["stream_hex"], tag
+            assert np.array_equal(codec.decode(np.frombuffer(bytes.fromhex(e["stream_hex"]), dtype=np.uint8), d.size), d), tag
+        assert np.array_equal(codec.decode(stream, d.size), d), tag
+    ctx.close()
+    # block containers: blocks of 16384 / 4096 / 512 ints, ragged ends, restart points
+    for shape, n, lg, block, ck in (("skew", 70001, 20, 16384, 1024), ("uniform", 40000, 22, 4096, 256), ("cluster", 33333, 17, 16384, 1024),
+                                    ("uniform", 3000, 24, 512, 0), ("skew", 16384 * 3, 22, 16384, 4096)):
+        d = ol.ansint_large_list(n, 1 << lg, 9 + lg, shape)
+        c1 = A.Context(0)
+        codec = A.ANSint(ctx=c1, block_ints=block, ckpt_interval=ck if ck else A.NO_CHECKPOINTS, compact=False)
+        cont = codec.encode(d)
+        assert c1.last_encode_stats()["path"] & 256
+        check_container(A, cont, d, ol.INT, 0, block, ck)
+        assert np.array_equal(codec.decode(cont, n), d)
+        assert np.array_equal(codec.encode(d), cont)  # (second call: rank space from the start)
+        # the same context, a list the dense model holds: the bytes a fresh context writes (parse hints included)
+        small = d % np.uint32(16384)
+        got = codec.encode(small)
+        assert not (c1.last_encode_stats()["path"] & 256)
+        c2 = A.Context(0)
+        fresh = A.ANSint(ctx=c2, block_ints=block, ckpt_interval=ck if ck else A.NO_CHECKPOINTS, compact=False).encode(small)
+        assert np.array_equal(got, fresh)
+        assert np.array_equal(codec.decode(got, n), small)
+        # ... and back
+        assert np.array_equal(codec.encode(d), cont)
+        c1.close()
+        c2.close()
+    # a block in which every int is a different large value (16384 ranks: the model's last symbol is used)
+    ctx = A.Context(0)
+    d = (np.arange(16384, dtype=np.uint32) * np.uint32(977) + np.uint32(50000))
+    codec = A.ANSint(ctx=ctx, block_ints=16384, ckpt_interval=1024, compact=False)
+    cont = codec.encode(d)
+    check_container(A, cont, d, ol.INT, 0, 16384, 1024)
+    assert np.array_equal(codec.decode(cont, d.size), d)
+    # a small case, as before: 16384 itself
+    d = np.array([1, 2, 16384, 3] * 100, dtype=np.uint32)
+    codec = A.ANSint(ctx=ctx, compact=False)
+    cont = codec.encode(d)
+    check_container(A, cont, d, ol.INT, 0, 16384, 1024)
+    assert np.array_equal(codec.decode(cont, d.size), d)
+    # out of reach: refused, not mis-coded
+    big = ol.ansint_large_list(40000, 1 << 20, 3, "uniform")
+    for kw in (dict(block_ints=A.SINGLE_STREAM), dict(block_ints=32768, ckpt_interval=1024)):
+        with pytest.raises(A.AnsxError) as ei:
+            A.ANSint(ctx=ctx, compact=False, **kw).encode(big)
+        assert ei.value.status == 6  # ANSX_ERR_DOMAIN
     with pytest.raises(A.AnsxError) as ei:
-        A.ANSint(ctx=ctx, compact=False).encode(np.array([1, 2, 16384, 3] * 100, dtype=np.uint32))
-    assert ei.value.status == 6  # ANSX_ERR_DOMAIN
+        A.ANSint(ctx=ctx, compact=False).encode(np.array([5, 1 << 30, 7], dtype=np.uint32))
+    assert ei.value.status == 6
+    ctx.close()
 
 
 def test_golden_compaction_fixtures(A, ctx):

@@ -373,3 +373,25 @@ def test_golden_plain_ansint_streams(oracle_built):
             assert hashlib.sha256(c.tobytes()).hexdigest() == e["stream_sha256"]
         assert np.array_equal(ol.oracle_decode(ol.INT, 0, s, d.size), d)
 
+
+def test_golden_plain_ansint_large_values(oracle_built):
+    """tests/golden/ansint_large.json (round 4): ans_int_compress bytes made by the real reference on lists whose values
+    reach 2^17, 2^20 and 2^22 -- the reference sizes its model by the largest value (ans_int.hpp:41-51); the restatement
+    stays dense, the GPU path models such lists in rank space (csrc/ansx_intsparse.h).  Where oracle/_ref is present the
+    reference itself is run on a few of them as well."""
+    with open(os.path.join(GOLD, "ansint_large.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold) == 36 and {e["log2_vmax"] for e in gold} == {17, 20, 22}
+    for e in gold:
+        d = ol.ansint_large_list(e["n"], 1 << e["log2_vmax"], e["seed"], e["shape"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == e["input_sha256"]
+        s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+        c = ol.canonicalize(s, info)
+        assert c.size == e["stream_len"] and info.log2_frame == e["log2_frame"] and info.prelude_bytes == e["prelude_bytes"]
+        assert hashlib.sha256(c.tobytes()).hexdigest() == e["stream_sha256"]
+        if "stream_hex" in e:
+            assert c.tobytes().hex() == e["stream_hex"]
+        assert np.array_equal(ol.oracle_decode(ol.INT, 0, s, d.size), d)
+        if ol.have_ref() and e["n"] in (7, 5000) and e["log2_vmax"] != 22:
+            assert np.array_equal(ol.canonicalize(ol.ref_encode(ol.INT, 0, d), info), c)
+

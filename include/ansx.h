@@ -55,10 +55,15 @@ typedef enum {
     ANSX_RFOLD = 1, /* ANSrfold<f> */
     ANSX_MSB = 2,   /* ANSmsb (include/methods.hpp:499-515 -> include/ans_msb.hpp); fidelity must be 0 */
     ANSX_INT = 3    /* ANSint, name() == "ANS" (include/methods.hpp:484-497 -> include/ans_int.hpp); fidelity must be 0.
-                       Its model spans every value up to the largest: plain, the values must be below 16384
-                       (ANSX_ERR_DOMAIN), block container or ANSX_SINGLE_STREAM (= the bytes of ans_int_compress);
-                       with ANSX_FLAG_COMPACT_ALPHABET any values, coded as a block's dense ranks.  32-bit
-                       frequencies: frames up to 2^27 (beyond, the reference's own 64-bit bound overflows) */
+                       Its model spans every value up to the largest (ans_int.hpp:41-51).  Plain: any values below 2^30,
+                       block container or ANSX_SINGLE_STREAM (= the bytes of ans_int_compress).  Lists whose values
+                       stay below 16384 use a dense model; beyond that every block is modelled over its distinct
+                       values (ranks) and only its prelude ranges over the values -- the same bytes -- which needs
+                       blocks (single-stream: lists) of at most 16384 ints: ANSX_ERR_DOMAIN otherwise, and for a block
+                       whose prelude would exceed 64 KiB (about 32 bits per distinct value).  The container's
+                       max_nsyms then bounds the ranks, not the values.  With ANSX_FLAG_COMPACT_ALPHABET: the
+                       harness's own layout, a block's dense ranks behind an alphabet header.  32-bit frequencies:
+                       frames up to 2^27 (beyond, the reference's own 64-bit bound overflows) */
 } ansx_kind;
 
 typedef enum {
@@ -211,7 +216,8 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             repeated with wide ones (remembered per geometry, but only as the attempt to run
  *                             FIRST); + 64: the remembered wide form was not needed by this input and the call was
  *                             repeated with packed restart points; + 128: the producer / consumer encoder kernel
- *                             (k_encode_pc) ran for the call's workgroups of 64 full blocks.  Either way the output bytes -- the restart-point
+ *                             (k_encode_pc) ran; + 256: plain ANSint modelled in rank space (values of 16384 and more; remembered per geometry
+ *                             as the attempt to run first, and given up again by a call whose values are small).  Either way the output bytes -- the restart-point
  *                             format included -- are a function of the input and the options only. */
 typedef struct {
     uint32_t max_nsyms;

@@ -67,6 +67,8 @@ struct ansx_ctx {
     std::map<std::array<u64, 4>, ansx_container_header> hdr_cache;
     std::deque<std::array<u64, 4>> hdr_order;  // keys of hdr_cache, oldest first (an erased key may linger: erase is idempotent)
     std::map<u32, DevBuf> geo;   // tree nodes of the interpolative code per alphabet size, tabulated per symbol-array size (<= 4096)
+    DevBuf geo_big;              // the same for alphabets up to geo_big_cap symbols (symbol arrays above 4096 slots, fast model path:
+    u32 geo_big_cap = 0;         //   sized from the geometry's alphabet hint, cap^2 * 4 bytes -- 284 MB for fidelity 5 on 2^20-valued lists)
     int last_gather_ranks = 0;   // ranks of the communicator the last ansx_gather_containers call ran on (ncclCommCount)
     std::set<u64> wide_hint;     // geometries that met a frame above 2^16: wide restart points from the start
     std::map<u64, u32> t_hint;   // largest chosen candidate index t (frame M0 * 2^t) + 1 seen per geometry: lanes per block of k_candidates
@@ -98,6 +100,7 @@ struct ansx_ctx {
         bool use_pc = false;          // ANSX_USE_PC: k_encode_pc's chip-filling shape even under ANSX_NO_PC_AUTO
         u32 pc_b_pairs = 2;           // ANSX_PC_B_PAIRS: pairs per workgroup of shape B (2: one workgroup per CU -- 1.04 ms on BASELINE config 3;
                                       // 1: two workgroups per CU, whose waves the dispatcher does not spread as evenly -- 1.21 ms)
+        bool no_big_geo = false;      // ANSX_NO_BIG_GEO: no tabulated tree geometry for alphabets above 4096 slots
         bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (shapes A, B, C of launch_f64_encoder)
         bool encode_mode2 = false;    // ANSX_ENCODE_MODE2: the compact-table encoder (k_encode<2>) even where the tables fit LDS (tests)
         bool force_pc = false;        // ANSX_FORCE_PC: the pair kernel for every workgroup of 64 full blocks, however few (tests)
@@ -612,6 +615,16 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
         && (NSP <= 4096 || (size_t)fcap_probe * 8 + 64 <= 150 * 1024) && !c->dbg.table16_fixup
         && !c->dbg.encode_gtab16 && (u64)scr_stride * 16 < 0x7FFFFF00ull;
     c->used_fast = fast;
+    if (fast && NSP > 4096 && !c->dbg.no_big_geo) {
+        // k_model_finish<0>: a 14-level tree descent per item was two thirds of its prelude writer; the nodes of every alphabet
+        // size up to the hint come from a table here too (built once per context, rebuilt when the hint grows)
+        if (c->geo_big_cap < fcap_probe) {
+            if ((rc = ensure(c, c->geo_big, ((size_t)fcap_probe * (fcap_probe + 1) / 2 + 8) * 8))) return rc;
+            LAUNCH(c, "k_build_interp_geo", k_build_interp_geo, fcap_probe, 256, 0, s, fcap_probe, (uint2*)c->geo_big.p);
+            c->geo_big_cap = fcap_probe;
+        }
+        geo = (const uint2*)c->geo_big.p;
+    }
     if (fast) {
         if ((rc = ensure(c, c->pairs, (size_t)NB * NSP * 8))) return rc;
         if (!c->lg2i.p) {  // log2 of the integers below 2^16, once per context (512 KB)
@@ -1783,6 +1796,7 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_FORCE_PC")) c->dbg.force_pc = on;
     else if (!strcmp(name, "ANSX_USE_PC")) c->dbg.use_pc = on;
     else if (!strcmp(name, "ANSX_NO_PC_AUTO")) c->dbg.no_pc_auto = on;
+    else if (!strcmp(name, "ANSX_NO_BIG_GEO")) c->dbg.no_big_geo = on;
     else if (!strcmp(name, "ANSX_PC_B_PAIRS")) c->dbg.pc_b_pairs = (value && value[0] == '1') ? 1u : 2u;
     else if (!strcmp(name, "ANSX_ENCODE_MODE2")) c->dbg.encode_mode2 = on;
     else if (!strcmp(name, "ANSX_DECODE_SMALL_RING"))
@@ -1821,7 +1835,7 @@ void ansx_destroy(ansx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = { &c->pre_work, &c->hist, &c->hterm, &c->sortF, &c->sortSym, &c->attS, &c->prevS, &c->attMeta, &c->blk,
         &c->table, &c->tab32, &c->scratch, &c->misc, &c->mapped, &c->mostfreq, &c->stage_in, &c->stage_out,
-        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes, &c->nearlist, &c->force };
+        &c->dec_s2s, &c->dec_cum, &c->dec_info, &c->plain, &c->rf_tmp, &c->log2lut, &c->pa_alpha, &c->pa_info, &c->pairs, &c->lg2i, &c->sizes, &c->nearlist, &c->force, &c->geo_big };
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : c->geo)

@@ -259,7 +259,8 @@ def compaction_rows(torch, A, ctx, device, n=64 * (1 << 20)):
             d_in = gen_input(torch, A, ctx, "zipf20s1.2", n, SEED, device)
         else:
             d_in = torch.from_numpy(host.view("int32")).to(device)
-        for label, cn, compact in (("ANSfold-1", "fold", False), ("ANSfold-1 + compaction", "fold", True), ("ANSint + compaction", "int", True)):
+        for label, cn, compact in (("ANSfold-1", "fold", False), ("ANSfold-1 + compaction", "fold", True), ("ANSint + compaction", "int", True),
+                                   ("ANSint plain (the reference's value-range prelude per block)", "intplain", False)):
             r = run_single(torch, A, ctx, device, cn, 1 if cn == "fold" else 0, name, n, 3, 2, d_in=d_in, compact=compact,
                            block=8192 if cn == "int" else 0, profile=False)
             rows.append({"input": name, "codec": label, "bits_per_int": r["bits_per_int"], "value": r["value"], "unit": "Mints/s",
@@ -432,6 +433,8 @@ def first_call_row(torch, ctx, codec, d_in, n, d_out, cap, d_back, stream):
 def make_codec(A, ctx, codec_name, fidelity, block=0, ckpt=0, compact=False):
     if codec_name == "int":
         return A.ANSint(ctx=ctx, block_ints=block, ckpt_interval=ckpt)
+    if codec_name == "intplain":  # the values themselves as symbols (ans_int.hpp): beyond 16384, a block's ranks (csrc/ansx_intsparse.h)
+        return A.ANSint(ctx=ctx, block_ints=block, ckpt_interval=ckpt, compact=False)
     if codec_name == "msb":
         return A.ANSmsb(ctx=ctx, block_ints=block, ckpt_interval=ckpt, compact=compact)
     cls = A.ANSfold if codec_name == "fold" else A.ANSrfold

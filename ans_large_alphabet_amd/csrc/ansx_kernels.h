@@ -2213,6 +2213,7 @@ __global__ __launch_bounds__(256) void k_encode(const u32* __restrict__ in, ansx
 // Host-checked: block_ints % 128 == 0 and <= 2^22, restart interval a multiple of 4 S.  The call's last workgroup may hold
 // blocks that do not exist and the partial last block: see "irregular" in the kernel.
 #define ANSX_PC_S 8  // (steps per batch of the default form; the kernel is a template over it)
+__device__ __forceinline__ void quad_transpose4(u32 (&v)[4], u32 ql);  // (defined with the decoder)
 __device__ __forceinline__ void pc_store_short_hi(u32 v, ansx_u32x4 rs, u32 voff)
 {
     asm volatile("buffer_store_short_d16_hi %0, %1, %2, 0 offen" : : "v"(v), "v"(voff), "s"(rs) : "memory");
@@ -2427,50 +2428,35 @@ __global__ __launch_bounds__(512) void k_encode_pc(const u32* __restrict__ in, a
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[3][0]), "+v"(w[3][1]) : : "memory");
             return;
         }
-        // byte offset of group (G - 32), this lane's state, in that view; a group before the block's first one gives an offset
-        // inside the previous block or beyond num_records (reads 0): never consumed
-        u32 vcur = (lane >> 2) * g.block_ints * 4 + 4 * (3 - ql) + 16 * (Gtot - ANSX_ENC_XB);
-        u32 xa[ANSX_ENC_XB];
-#define ANSX_XLOAD(dst, voff, j) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(irs), "s"(16 * (ANSX_ENC_XB - 1 - (j))) : "memory")
+        if constexpr (S == 4) {
+        // S = 4 (two pairs per workgroup, each wave alone on its SIMD: LDS has no room for input strips, the producer has
+        // instruction slots to spare): the 4 groups of a batch are 64 contiguous bytes of the quad's block; lane l loads group
+        // (base + 3 - l) as ONE 16-byte load, reverses its elements (a renaming) and the quad transposes 4 x 4 (quad_transpose4,
+        // 8 DPP moves + 8 selects per batch): v[i] = element (3 - l) of group base + 3 - i = this lane's input of step i.  A quarter
+        // of the load requests of the dword-per-step form, each a whole 16-byte piece.  Eight batches in flight.
+        const u32 vq4 = (lane >> 2) * g.block_ints * 4 + 16u * (3u - ql);
+        ansx_u32x4 wq[8];
+        auto request4 = [&](u32 batch, ansx_u32x4& d) {
+            // groups Gtot - 4 batch - 4 .. Gtot - 4 batch - 1; a batch behind the last one: an offset beyond num_records -- never consumed
+            const u32 off = vq4 + 16u * (Gtot - 4u * batch - 4u);
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(off), "s"(irs) : "memory");
+        };
 #pragma unroll
-        for (int j = 0; j < ANSX_ENC_XB; j++) ANSX_XLOAD(xa[j], vcur, j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < ANSX_ENC_XB; i += 8)
-            asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
-                         "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
+        for (int j = 0; j < 7; j++) request4((u32)j, wq[j]);
         for (u32 sb = 0; sb < Gtot / ANSX_ENC_XB; sb++) {
-            const u32 vnext = vcur - 16 * ANSX_ENC_XB;
 #pragma unroll
-            for (int t = 0; t < ANSX_ENC_XB / S; t++) {
-                // the S registers the previous batch released take the inputs of their steps in the next super-batch (the
-                // last S of THIS one when requested at step 0, which they hold already)
-#pragma unroll
-                for (int i = 0; i < S; i++) {
-                    const int e = (t * S + ANSX_ENC_XB - S + i) % ANSX_ENC_XB;
-                    if (t == 0) ANSX_XLOAD(xa[e], vcur, e);
-                    else ANSX_XLOAD(xa[e], vnext, e);
-                }
-                // this batch's registers were requested 32 / S - 1 requests ago: 32 - S younger loads are in flight
-                asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-                static_assert(S == 4 || S == 8, "");
-#pragma unroll
-                for (int i = 0; i < S; i++) asm volatile("" : "+v"(xa[t * S + i]));
-                u32 xs_[S];
-#pragma unroll
-                for (int i = 0; i < S; i++) xs_[i] = xa[t * S + i];
-                emit(xs_, Gtot - (u32)S * pb, hbase + (pb & 1u) * (S * 1024));
+            for (int t = 0; t < 8; t++) {
+                request4(pb + 7, wq[(t + 7) % 8]);
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(wq[t]) : : "memory");  // seven younger requests
+                u32 xs_[4] = { wq[t].w, wq[t].z, wq[t].y, wq[t].x };
+                quad_transpose4(xs_, ql);
+                emit(xs_, Gtot - 4u * pb, hbase + (pb & 1u) * (S * 1024));
                 pb++;
                 __syncthreads();
             }
-            vcur = vnext;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < ANSX_ENC_XB; i += 8)
-            asm volatile("" : "+v"(xa[i]), "+v"(xa[i + 1]), "+v"(xa[i + 2]), "+v"(xa[i + 3]), "+v"(xa[i + 4]),
-                         "+v"(xa[i + 5]), "+v"(xa[i + 6]), "+v"(xa[i + 7]));
-#undef ANSX_XLOAD
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(wq[4]), "+v"(wq[5]), "+v"(wq[6]), "+v"(wq[7]) : : "memory");
+        }
         return;
     }
     // -------------------------------------------------------------------- consumer

@@ -295,7 +295,7 @@ def pmc_traffic(kernel, workload):
             base = name.split("<")[0]
             # profile labels are the launch sites' ("k_decode", "k_encode_gtab"), the PMC summary has the
             # kernels' own names ("k_decode_rank<...>", "k_encode<2, ...>")
-            if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel == "k_encode_gtab" and base == "k_encode") \
+            if base == kernel or (kernel == "k_decode" and base == "k_decode_rank") or (kernel in ("k_encode_gtab", "k_encode") and base in ("k_encode", "k_encode_pc")) \
                     or (kernel == "k_rfold_remap" and base.startswith("k_rfold_remap")):
                 return v["hbm_bytes"], "replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % rel
         return None, "%s has no entry for %s" % (rel, kernel)

@@ -100,6 +100,7 @@ struct ansx_ctx {
         bool use_pc = false;          // ANSX_USE_PC: k_encode_pc's chip-filling shape even under ANSX_NO_PC_AUTO
         u32 pc_b_pairs = 2;           // ANSX_PC_B_PAIRS: pairs per workgroup of shape B (2: one workgroup per CU -- 1.04 ms on BASELINE config 3;
                                       // 1: two workgroups per CU, whose waves the dispatcher does not spread as evenly -- 1.21 ms)
+        bool fin_one_wave = false;    // ANSX_FIN_ONE_WAVE: k_model_finish with one wave per block (alphabets up to 1024 slots)
         bool no_big_geo = false;      // ANSX_NO_BIG_GEO: no tabulated tree geometry for alphabets above 4096 slots
         bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (shapes A, B, C of launch_f64_encoder)
         bool encode_mode2 = false;    // ANSX_ENCODE_MODE2: the compact-table encoder (k_encode<2>) even where the tables fit LDS (tests)
@@ -725,7 +726,18 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo, \
             fin_generic ? hist : (u32*)nullptr); \
     } while (0)
-        if (NSP <= 1024) {
+        if (NSP <= 1024 && c->dbg.fin_one_wave) {
+            // one wave per block (16 slots per lane, every candidate in every lane, no workgroup barriers): four times the blocks in flight
+            if (NT <= 5) {
+                LAUNCH(c, "k_model_finish", (k_model_finish<16, 5, 64>), NB, 64, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
+                    (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo,
+                    (u32*)nullptr);
+            } else {
+                LAUNCH(c, "k_model_finish", (k_model_finish<16, 8, 64>), NB, 64, fl, s, g, NSP, NT, (const uint2*)c->pairs.p, (const uint4*)c->attS.p,
+                    (const u32*)c->attMeta.p, blk, (u32*)c->tab32.p, (u8*)c->scratch.p, (u64)scr_stride, mostfreq, hints, gflags, fcap, c->dbg.fast_guard, (const double*)c->lg2i.p, geo,
+                    (u32*)nullptr);
+            }
+        } else if (NSP <= 1024) {
             ANSX_LAUNCH_FIN(4, 8);  // (wave-per-candidate form: NTC is not used)
         } else if (NSP > 4096) {
             if (NT <= 5) ANSX_LAUNCH_FIN(0, 5);
@@ -1797,6 +1809,7 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_USE_PC")) c->dbg.use_pc = on;
     else if (!strcmp(name, "ANSX_NO_PC_AUTO")) c->dbg.no_pc_auto = on;
     else if (!strcmp(name, "ANSX_NO_BIG_GEO")) c->dbg.no_big_geo = on;
+    else if (!strcmp(name, "ANSX_FIN_ONE_WAVE")) c->dbg.fin_one_wave = on;
     else if (!strcmp(name, "ANSX_PC_B_PAIRS")) c->dbg.pc_b_pairs = (value && value[0] == '1') ? 1u : 2u;
     else if (!strcmp(name, "ANSX_ENCODE_MODE2")) c->dbg.encode_mode2 = on;
     else if (!strcmp(name, "ANSX_DECODE_SMALL_RING"))

@@ -266,20 +266,21 @@ __global__ __launch_bounds__(64 * ANSX_CAND_WAVES) void k_candidates(ansx_geo g,
 // Anything this path does not cover raises the violation flag and leaves the block without a stream; the host
 // repeats the call on the exact path: undecided after NT candidates, the u16 exit with no earlier success, a
 // frame above 2^16, a comparison inside the guard band (`guard`: ANSX_FAST_GUARD; tests widen it to force the repeat).
-template <int IPT, int NTC>
-__global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 NT, const uint2* __restrict__ pairs,
+template <int IPT, int NTC, int NTH = 256>
+__global__ __launch_bounds__(NTH) void k_model_finish(ansx_geo g, u32 NSP, u32 NT, const uint2* __restrict__ pairs,
     const uint4* __restrict__ srank, const u32* __restrict__ attMeta, ansx_blk* __restrict__ blk,
     u32* __restrict__ tab32, u8* __restrict__ scratch, u64 scr_stride, const u32* __restrict__ mostfreq,
     u32* __restrict__ hints, u32* __restrict__ gflags, u32 cap, double guard, const double* __restrict__ lg2i,
     const uint2* __restrict__ geo, u32* __restrict__ incbuf = nullptr)
 {
     static_assert(IPT % 4 == 0, "table rows are written 16 bytes at a time");
-    static_assert(ANSX_FIN_LUT == 512, "two table entries per thread");
+    static_assert(ANSX_FIN_LUT == 512 && (NTH == 256 || NTH == 64), "two table entries per thread (eight in the one-wave form)");
+    static_assert(NTH == 256 || (IPT > 4), "the one-wave form takes every candidate in every lane");
     static_assert(NTC >= 4 && NTC <= (int)ANSX_ATTEMPTS, "candidates per block");
     extern __shared__ u32 lds32[];
     __shared__ u32 sh_part[8];
     __shared__ double lut[ANSX_FIN_LUT];
-    __shared__ double wpart[ANSX_ATTEMPTS][4];  // per candidate and wave: partial sum of F log2 S
+    __shared__ double wpart[ANSX_ATTEMPTS][4];  // per candidate and wave: partial sum of F log2 S (one wave: column 0)
     __shared__ double wsum[ANSX_ATTEMPTS];      // XH of every candidate
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const u32 b = blockIdx.x;
@@ -305,7 +306,9 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     uint2 mt[ANSX_ATTEMPTS];
 #pragma unroll
     for (u32 t = 0; t < ANSX_ATTEMPTS; t++) mt[t] = t < NT ? *(const uint2*)(attMeta + ((u64)b * ANSX_ATTEMPTS + t) * 4) : make_uint2(0u, 0u);
-    const double2 l2 = *(const double2*)(lg2i + 2 * tid);
+    double2 l2[256 / NTH];
+#pragma unroll
+    for (int i = 0; i < 256 / NTH; i++) l2[i] = *(const double2*)(lg2i + 2 * (tid + NTH * i));
     const uint2* prow = pairs + (u64)b * NSP;
     auto load_fs = [&](u32 c, u32 (&fs)[8]) {
         const uint2* pp = prow + (u64)c * 8u;
@@ -353,8 +356,9 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         if (tid == 0) B->prelude_bytes = 0;
         return;
     }
-    for (u32 s = tid; s < cap; s += 256) frq[s] = 0;  // absent symbols have frequency 0
-    *(double2*)(lut + 2 * tid) = l2;
+    for (u32 s = tid; s < cap; s += NTH) frq[s] = 0;  // absent symbols have frequency 0
+#pragma unroll
+    for (int i = 0; i < 256 / NTH; i++) *(double2*)(lut + 2 * (tid + NTH * i)) = l2[i];
     STAMP(1);
     __syncthreads();
     STAMP(2);
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             for (int t = 0; t < NTC; t++)
                 if ((u32)t < NT) w[t] = xh8(fs0, sv0[t]);
         }
-        for (u32 c = tid + 256u; c < nchunks; c += 256u) {  // alphabets above 2048 symbols: a second round trip
+        for (u32 c = tid + NTH; c < nchunks; c += NTH) {  // alphabets above 8 NTH symbols: a second round trip
             u32 fs1[8];
             uint4 s1[NTC];
             load_fs(c, fs1);
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             for (int t = 0; t < NTC; t++)
                 if ((u32)t < NT) w[t] = w[t] + xh8(fs1, s1[t]);
         }
-        if (wv * 64u < nchunks || nchunks > 256u) {  // (waves without a chunk have nothing to add)
+        if (wv * 64u < nchunks || nchunks > (u32)NTH) {  // (waves without a chunk have nothing to add)
 #pragma unroll
             for (int t = 0; t < NTC; t++) {
                 if ((u32)t >= NT) continue;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
         } else if (lane < NTC) wpart[lane][wv] = 0.0;
         STAMP(3);
         __syncthreads();
-        if (tid < NT) wsum[tid] = (double)(m0 + tid) - ((wpart[tid][0] + wpart[tid][1]) + (wpart[tid][2] + wpart[tid][3])) / nd;  // one division per candidate
+        if (tid < NT) wsum[tid] = (double)(m0 + tid) - (NTH == 64 ? wpart[tid][0] : (wpart[tid][0] + wpart[tid][1]) + (wpart[tid][2] + wpart[tid][3])) / nd;  // one division per candidate
         __syncthreads();
     } else {
         auto xh_chunk = [&](const chunk& k) -> double {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
                 if (chosen == t) sc = sv0[t];
             scatter(fs0, sc, tid);
         }
-        for (u32 c = tid + 256u; c < nchunks; c += 256u) {
+        for (u32 c = tid + NTH; c < nchunks; c += NTH) {
             u32 fs1[8];
             load_fs(c, fs1);
             scatter(fs1, srank[srank_chunk(NSP, NT, b, c, (u32)chosen)], c);
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
             fr[i] = f4.x, fr[i + 1] = f4.y, fr[i + 2] = f4.z, fr[i + 3] = f4.w;
             sum += f4.x + f4.y + f4.z + f4.w;
         }
-        u32 base = block_excl_scan<u32>(sum, sh_part, tid, 256, &total);
+        u32 base = block_excl_scan<u32>(sum, sh_part, tid, NTH, &total);
         STAMP(7);
         if (s0 < ns) {
             u32* t32 = tab32 + (u64)b * NSP + s0;
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(256) void k_model_finish(ansx_geo g, u32 NSP, u32 N
     STAMP(9);
 #ifndef FIN_NO_PRELUDE
     // (IPT == 0 serves alphabets up to 16384 slots here: 64 items per thread at most, their codes kept in registers)
-    prelude_emit<IPT, false, true, IPT == 0 ? 8 : 0>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (logM <= 16)
+    prelude_emit<IPT, false, true, IPT == 0 ? 8 : 0, NTH>(g, B, ns, logM, inc, off, bits, sh_part, scratch + (u64)b * scr_stride, mostfreq, b, tid, 0, hints, geo);  // (logM <= 16)
 #endif
     STAMP(10);
 }

@@ -1112,13 +1112,14 @@ __device__ __forceinline__ void interp_items8(const u32* __restrict__ inc, u32 n
 // KEEP8 (IPT == 0 only): the caller guarantees ns <= 2048 * KEEP8; the codes of a thread's <= 8 KEEP8 items stay in
 // registers between the two passes (two words each) instead of being derived again -- on alphabets beyond the tabulated
 // tree geometry (> 4096 slots) a derivation is a 14-level descent per item, half of the writer's time there.
-template <int IPT, bool PA = false, bool W32 = false, int KEEP8 = 0>
+template <int IPT, bool PA = false, bool W32 = false, int KEEP8 = 0, int NTH = 256>
 __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32 ns, u32 logM, const u32* inc,
     u32* off, u32* bits, u32* sh_part, u8* __restrict__ out, const u32* __restrict__ mostfreq, u32 b, u32 tid,
     u64 uni = 0, u32* __restrict__ hints = nullptr, const uint2* __restrict__ geo = nullptr)
 {
     const uint2* const geo_row = (geo != nullptr && ns >= 1) ? geo + interp_geo_row(ns) : nullptr;  // (tabulated tree nodes)
     constexpr bool SMALL = IPT > 0;
+    static_assert(NTH == 256 || IPT > 0, "the eight-items-per-round form strides by 256 threads");
     typedef typename std::conditional<W32, u32, u64>::type W;
     const W u = (W)(PA ? uni : ((u64)1 << logM) + ns + 1);  // ans_util.hpp:60
     ansx_code mine[SMALL ? IPT : 1];
@@ -1127,7 +1128,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
     if (SMALL) {
 #pragma unroll
         for (int j = 0; j < (SMALL ? IPT : 1); j++) {
-            const u32 i = tid + 256 * j;
+            const u32 i = tid + NTH * j;
             mine[j].len = 0;
             if (i < ns) {
                 mine[j] = interp_item<W>(inc, ns, u, i, geo_row);
@@ -1140,7 +1141,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         if constexpr (KEEP8 > 0) {
 #pragma unroll
             for (int r = 0; r < KEEP8; r++) {
-                const u32 i0 = tid + 2048u * (u32)r;
+                const u32 i0 = tid + 8u * NTH * (u32)r;
 #pragma unroll
                 for (u32 j = 0; j < 8; j++) kept_code[8 * r + j] = 0, kept_lr[8 * r + j] = 0;
                 if (i0 < ns) {
@@ -1148,37 +1149,37 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
                     interp_items8<W>(inc, ns, u, i0, geo_row, c8);
 #pragma unroll
                     for (u32 j = 0; j < 8; j++) {
-                        if (i0 + 256 * j < ns) off[c8[j].rank] = c8[j].len;
+                        if (i0 + NTH * j < ns) off[c8[j].rank] = c8[j].len;
                         kept_code[8 * r + j] = c8[j].code;
                         kept_lr[8 * r + j] = c8[j].len | (c8[j].rank << 8);  // (len 0 beyond ns)
                     }
                 }
             }
         } else
-        for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
+        for (u32 i0 = tid; i0 < ns; i0 += NTH * 8) {
             ansx_code c8[8];
             interp_items8<W>(inc, ns, u, i0, geo_row, c8);
 #pragma unroll
             for (u32 j = 0; j < 8; j++)
-                if (i0 + 256 * j < ns) off[c8[j].rank] = c8[j].len;
+                if (i0 + NTH * j < ns) off[c8[j].rank] = c8[j].len;
         }
         __threadfence_block();  // (off[] and the bit buffer may live in HBM on this path)
     }
     __syncthreads();
     // exclusive scan of off[0..ns)
-    const u32 per = (ns + 255) / 256;
+    const u32 per = (ns + NTH - 1) / NTH;
     const u32 lo = tid * per, hi = (lo + per) < ns ? (lo + per) : ns;
     u32 sum = 0;
     for (u32 s = lo; s < hi; s++) sum += off[s];
     u32 total_bits;
-    u32 run = block_excl_scan<u32>(sum, sh_part, tid, 256, &total_bits);
+    u32 run = block_excl_scan<u32>(sum, sh_part, tid, NTH, &total_bits);
     for (u32 s = lo; s < hi; s++) {
         u32 t = off[s];
         off[s] = run;
         run += t;
     }
     const u32 nwords = (total_bits + 31) >> 5;
-    for (u32 w = tid; w <= nwords; w += 256) bits[w] = 0;
+    for (u32 w = tid; w <= nwords; w += NTH) bits[w] = 0;
     if (!SMALL) __threadfence_block();
     __syncthreads();
     if (!PA && hints != nullptr && tid < 8) {
@@ -1228,7 +1229,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
                 place(c);
             }
         } else
-        for (u32 i0 = tid; i0 < ns; i0 += 256 * 8) {
+        for (u32 i0 = tid; i0 < ns; i0 += NTH * 8) {
             ansx_code c8[8];
             interp_items8<W>(inc, ns, u, i0, geo_row, c8);
 #pragma unroll
@@ -1244,7 +1245,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
             st_u32_unaligned(out + 4, (u32)uni);
             B->pre_bytes = 8 + nbytes;
         }
-        for (u32 j = tid; j < nbytes; j += 256) out[8 + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
+        for (u32 j = tid; j < nbytes; j += NTH) out[8 + j] = (u8)(bits[j >> 2] >> (8 * (j & 3)));
         return;
     }
     const u32 p0 = B->pre_bytes;
@@ -1256,7 +1257,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         p += 4;
         if (flag) {
             const u32* mf = mostfreq + (u64)b * T;
-            for (u32 i = tid; i < T; i += 256) st_u32_unaligned(out + p + 4 * (u64)i, mf[i]);
+            for (u32 i = tid; i < T; i += NTH) st_u32_unaligned(out + p + 4 * (u64)i, mf[i]);
             p += 4 * T;
         }
     }
@@ -1276,7 +1277,7 @@ __device__ __forceinline__ void prelude_emit(const ansx_geo& g, ansx_blk* B, u32
         out[q] = (u8)logM;
     }
     p += vb + 1;
-    for (u32 w = tid; w < nwords; w += 256) st_u32_unaligned(out + p + 4 * w, bits[w]);  // (any byte alignment)
+    for (u32 w = tid; w < nwords; w += NTH) st_u32_unaligned(out + p + 4 * w, bits[w]);  // (any byte alignment)
     if (tid == 0) {
         B->hdr_bytes = hdr;
         B->prelude_bytes = p + nbytes;

@@ -585,7 +585,6 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     const bool sparse = c->cur_int_sparse;
     if (sparse) {
         // plain ANSint on values beyond the dense model (ansx_intsparse.h): the codec runs on every block's 0-based ranks
-        if (g.block_ints > ANSX_PA_MAX_BLOCK) return ANSX_ERR_DOMAIN;  // (the per-block remap holds a block in one CU's LDS)
         if ((rc = ensure(c, c->mapped, (size_t)NB * g.block_ints * 4))) return rc;
         if ((rc = ensure(c, c->pa_alpha, (size_t)NB * g.block_ints * 4))) return rc;
         const size_t lds1 = ((size_t)ANSX_PA_SLOTS + ANSX_PA_MAX_BLOCK) * 4;
@@ -1133,7 +1132,7 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
     u32 seen = 0;
     int rc = ANSX_RETRY_GENERAL;
     const bool int_plain = P.g.kind == ANSX_INT && !P.g.pa;
-    c->cur_int_sparse = int_plain && c->int_sparse_hint.count(key) != 0 && P.g.block_ints <= ANSX_PA_MAX_BLOCK;
+    c->cur_int_sparse = int_plain && c->int_sparse_hint.count(key) != 0;
     const auto it = c->ns_hint.find(key);
     const u32 hint = c->dbg.ns_hint ? c->dbg.ns_hint : (it != c->ns_hint.end() ? it->second : 0u);
     const bool eligible = !P.plain && hint != 0 && (P.NSP <= 4096 || (P.NSP <= 16384 && P.g.kind != ANSX_INT && !P.g.pa)) && !c->dbg.encode_gtab16 && !c->dbg.table16_fixup
@@ -1169,7 +1168,7 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
     // Plain ANSint: the dense model takes values below 16384; a call with larger ones is repeated in rank space, and so is
     // every later call of the geometry from the start -- unless its values turn out small, where the dense form (whose
     // containers carry parse hints) is the one a fresh context would have written: equal inputs, equal bytes.
-    if (int_plain && !c->cur_int_sparse && rc == ANSX_ERR_DOMAIN && P.g.block_ints <= ANSX_PA_MAX_BLOCK) {
+    if (int_plain && !c->cur_int_sparse && rc == ANSX_ERR_DOMAIN) {
         c->cur_int_sparse = true;
         c->int_sparse_hint.insert(key);
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);

@@ -60,12 +60,17 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
     // waited a global round trip that this one workgroup per CU has nothing to hide behind.
     constexpr u32 PA_VPT = ANSX_PA_MAX_BLOCK / 1024;
     u32 vals[PA_VPT];
-#pragma unroll
-    for (u32 q = 0; q < PA_VPT; q++) vals[q] = tid + q * nt < nb ? src[tid + q * nt] : 0u;
     u32 lmax = 0;
+    // (mode 1 takes blocks of any length -- a whole list in single-stream mode -- 16 Ki ints at a time: what bounds it is the
+    // number of DISTINCT values, uqcap)
+    const u32 nchunks = mode == 1 ? (nb + ANSX_PA_MAX_BLOCK - 1) / ANSX_PA_MAX_BLOCK : 1u;
+    for (u32 ch = 0; ch < nchunks; ch++) {
+    const u32 cbase = ch * ANSX_PA_MAX_BLOCK;
+#pragma unroll
+    for (u32 q = 0; q < PA_VPT; q++) vals[q] = cbase + tid + q * nt < nb ? src[cbase + tid + q * nt] : 0u;
 #pragma unroll
     for (u32 q = 0; q < PA_VPT; q++) {
-        if (tid + q * nt >= nb) break;
+        if (cbase + tid + q * nt >= nb) break;
         const u32 v = vals[q];
         lmax = v > lmax ? v : lmax;
         u32 slot = pa_slot(v, slots);
@@ -81,8 +86,22 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
         }
         if (probes == slots) sh_ovf = 1;  // table full (only possible below the full size)
     }
+    if (nchunks > 1) {  // (a list with too many distinct values: give up after the chunk that showed it, not after the list)
+        __syncthreads();
+        if (sh_ovf || sh_cnt > uqcap) break;
+    }
+    }
     atomicMax(&sh_max, lmax);
     __syncthreads();
+    if (mode == 1 && (sh_ovf || sh_cnt > uqcap)) {  // more distinct values than the rank-space model has symbols: ANSX_ERR_DOMAIN
+        for (u32 i = tid; i < nb; i += nt) dst[i] = 0;
+        if (tid == 0) {
+            alpha_sum[(u64)b * g.block_ints] = 0;
+            blk[b].sp_sigma = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << 6);
+        }
+        return;
+    }
     if (sh_ovf || sh_cnt > uqcap) {  // optimistic sizes too small: a valid one-value block, and the call is repeated
         for (u32 i = tid; i < nb; i += nt) dst[i] = 1;
         if (tid == 0) {
@@ -185,7 +204,12 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
     // 1-based rank of every value (:91-103): branch-free lower bound over the padded, sorted array (the padding
     // compares above every value), the thread's 16 searches advancing together -- 16 independent LDS reads per step
     __syncthreads();
-    {
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        const u32 cbase = ch * ANSX_PA_MAX_BLOCK;
+        if (nchunks > 1) {  // (a single chunk's values are still in registers)
+#pragma unroll
+            for (u32 q = 0; q < PA_VPT; q++) vals[q] = cbase + tid + q * nt < nb ? src[cbase + tid + q * nt] : 0u;
+        }
         u32 lo[PA_VPT];
 #pragma unroll
         for (u32 q = 0; q < PA_VPT; q++) lo[q] = 0;
@@ -198,7 +222,7 @@ __device__ __forceinline__ void pa_remap_body(const u32* __restrict__ in, const 
         }
 #pragma unroll
         for (u32 q = 0; q < PA_VPT; q++)
-            if (tid + q * nt < nb) dst[tid + q * nt] = lo[q] + (mode == 1 ? 0u : 1u);
+            if (cbase + tid + q * nt < nb) dst[cbase + tid + q * nt] = lo[q] + (mode == 1 ? 0u : 1u);
     }
 }
 

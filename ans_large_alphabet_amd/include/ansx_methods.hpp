@@ -112,7 +112,7 @@ using ANSmsbGPUStream = ansx::Codec<ANSX_MSB, 0u, ANSX_SINGLE_STREAM>;
 // per-block alphabet compaction of src/pseudo_adaptive.cpp:85-130 (every block = alphabet header + ANSint
 // stream of the block's 1-based ranks, as that harness writes it), which is also available for the others
 using ANSintGPU = ansx::Codec<ANSX_INT, 0u, 0u, ANSX_FLAG_COMPACT_ALPHABET>;
-// ANSint on the values themselves (any below 2^30; from 16384 on: blocks / single-stream lists of at most 16384 ints): block container, or exactly the bytes of ANSint::encode
+// ANSint on the values themselves (any below 2^30; from 16384 on: blocks / single-stream lists with at most 16384 distinct values): block container, or exactly the bytes of ANSint::encode
 using ANSintGPUPlain = ansx::Codec<ANSX_INT, 0u, 0u>;
 using ANSintGPUStream = ansx::Codec<ANSX_INT, 0u, ANSX_SINGLE_STREAM>;
 using ANSmsbGPUCompact = ansx::Codec<ANSX_MSB, 0u, 0u, ANSX_FLAG_COMPACT_ALPHABET>;

@@ -58,8 +58,9 @@ typedef enum {
                        Its model spans every value up to the largest (ans_int.hpp:41-51).  Plain: any values below 2^30,
                        block container or ANSX_SINGLE_STREAM (= the bytes of ans_int_compress).  Lists whose values
                        stay below 16384 use a dense model; beyond that every block is modelled over its distinct
-                       values (ranks) and only its prelude ranges over the values -- the same bytes -- which needs
-                       blocks (single-stream: lists) of at most 16384 ints: ANSX_ERR_DOMAIN otherwise, and for a block
+                       values (ranks) and only its prelude ranges over the values -- the same bytes -- which takes
+                       blocks (single-stream: lists) of any length with at most 16384 DISTINCT values each:
+                       ANSX_ERR_DOMAIN otherwise, and for a block
                        whose prelude would exceed 64 KiB (about 32 bits per distinct value).  The container's
                        max_nsyms then bounds the ranks, not the values.  With ANSX_FLAG_COMPACT_ALPHABET: the
                        harness's own layout, a block's dense ranks behind an alphabet header.  32-bit frequencies:

@@ -71,6 +71,18 @@ def main():
                 if n <= 1000:
                     row["stream_hex"] = ol.canonicalize(raw, info).tobytes().hex()
                 big.append(row)
+    # lists longer than one block's worth: what bounds the rank-space model is the number of DISTINCT values (16384)
+    for shape, n, lg in (("cluster", 100000, 20), ("cluster", 300001, 22), ("cluster", 65536, 17)):
+        seed = 4100 + lg
+        d = ol.ansint_large_list(n, 1 << lg, seed, shape)
+        raw = ol.ref_encode(ol.INT, 0, d)
+        s, info, _, _ = ol.oracle_encode(ol.INT, 0, d)
+        assert raw.size == s.size and np.array_equal(ol.ref_decode(ol.INT, 0, raw, n), d)
+        assert np.array_equal(ol.canonicalize(raw, info), ol.canonicalize(s, info))
+        big.append({"shape": shape, "n": n, "log2_vmax": lg, "seed": seed, "log2_frame": int(info.log2_frame),
+                    "prelude_bytes": int(info.prelude_bytes), "stream_len": int(raw.size), "distinct": int(np.unique(d).size),
+                    "input_sha256": hashlib.sha256(d.tobytes()).hexdigest(),
+                    "stream_sha256": hashlib.sha256(ol.canonicalize(raw, info).tobytes()).hexdigest()})
     with open(os.path.join(HERE, "ansint_large.json"), "w") as fh:
         json.dump(big, fh, indent=0)
     print("ansint_large.json:", len(big), "entries; preludes", min(r["prelude_bytes"] for r in big), "..", max(r["prelude_bytes"] for r in big), "bytes")

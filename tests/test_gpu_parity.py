@@ -1572,7 +1572,8 @@ def test_plain_ansint_beyond_the_dense_model(A):
     space per block (csrc/ansx_intsparse.h) and only the prelude ranges over the values: single-stream bytes equal the
     reference's (tests/golden/ansint_large.json, made by oracle/_ref: max values 2^17, 2^20, 2^22), reference-made streams
     decode, every block of a container is the oracle's stream, and the bytes do not depend on what the context encoded
-    before.  What stays out of reach is refused, not mis-coded: blocks longer than 16384 ints with such values."""
+    before.  The rank-space model has 16384 symbols: a block (in single-stream mode: the list) of any length with at most
+    that many DISTINCT values is in reach; beyond, the call is refused, not mis-coded."""
     with open(os.path.join(GOLD, "ansint_large.json")) as fh:
         gold = json.load(fh)
     ctx = A.Context(0)
@@ -1626,7 +1627,14 @@ def test_plain_ansint_beyond_the_dense_model(A):
     cont = codec.encode(d)
     check_container(A, cont, d, ol.INT, 0, 16384, 1024)
     assert np.array_equal(codec.decode(cont, d.size), d)
-    # out of reach: refused, not mis-coded
+    # long blocks with few distinct large values: a 65536-int block geometry and a whole list as one stream
+    d = ol.ansint_large_list(200000, 1 << 21, 77, "cluster")
+    codec = A.ANSint(ctx=ctx, block_ints=65536, ckpt_interval=1024, compact=False)
+    cont = codec.encode(d)
+    assert ctx.last_encode_stats()["path"] & 256
+    check_container(A, cont, d, ol.INT, 0, 65536, 1024)
+    assert np.array_equal(codec.decode(cont, d.size), d)
+    # out of reach (more than 16384 distinct values in a block): refused, not mis-coded
     big = ol.ansint_large_list(40000, 1 << 20, 3, "uniform")
     for kw in (dict(block_ints=A.SINGLE_STREAM), dict(block_ints=32768, ckpt_interval=1024)):
         with pytest.raises(A.AnsxError) as ei:

@@ -686,7 +686,9 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     // scratch slots too far apart for the f64 encoder's 31-bit buffer offsets)
     const bool test_fixup = c->dbg.table16_fixup;  // tests: integer-state encoder fed by k_table16_from32
     const u32 always16 = (!test_fixup && (NSP > 4096 || (u64)scr_stride * 16 >= 0x7FFFFF00ull || c->dbg.encode_gtab16)) ? 1u : 0u;
-    u32* hints = P.plain ? nullptr : (u32*)(d_out + P.lay.hint_off);
+    // (plain ANSint: no parse hints -- its decoder walks the value-range prelude sparsely, and the container must not depend on
+    // which of the two models, dense or rank space, wrote it)
+    u32* hints = (P.plain || (g.kind == ANSX_INT && !g.pa)) ? nullptr : (u32*)(d_out + P.lay.hint_off);
     if (fast) {
         const u32 bpw = 64u / NT;
         // chains per lane: one while that leaves at most one wave per SIMD, else two (see k_candidates)

@@ -2681,7 +2681,8 @@ __global__ void k_write_header(ansx_geo g, u8* __restrict__ out, const u32* __re
     w[1] = g.ckpt;
     w[2] = g.nblocks;
     w[3] = gflags[ANSX_G_MAXLOGM];
-    w[4] = gflags[ANSX_G_MAXNSYMS];
+    // (plain ANSint: the bound on a block's DISTINCT values -- the same whether the call ran the dense model or the rank-space one)
+    w[4] = (g.kind == 3 && !g.pa) ? gflags[ANSX_G_MAXSIGMA] : gflags[ANSX_G_MAXNSYMS];
     w[5] = g.nckf;
     *(u64*)(out + 48) = result[0];
     *(u64*)(out + 56) = payload_off;
@@ -2734,7 +2735,7 @@ __global__ __launch_bounds__(256) void k_assemble(ansx_geo g, const u32* __restr
                 w[1] = g.ckpt;
                 w[2] = g.nblocks;
                 w[3] = __hip_atomic_load(&gflags[ANSX_G_MAXLOGM], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w[4] = __hip_atomic_load(&gflags[ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w[4] = __hip_atomic_load(&gflags[(g.kind == 3 && !g.pa) ? ANSX_G_MAXSIGMA : ANSX_G_MAXNSYMS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (see k_write_header)
                 w[5] = g.nckf;
                 *(u64*)(out + 48) = total;
                 *(u64*)(out + 56) = payload_off;

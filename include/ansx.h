@@ -61,8 +61,9 @@ typedef enum {
                        values (ranks) and only its prelude ranges over the values -- the same bytes -- which takes
                        blocks (single-stream: lists) of any length with at most 16384 DISTINCT values each:
                        ANSX_ERR_DOMAIN otherwise, and for a block
-                       whose prelude would exceed 64 KiB (about 32 bits per distinct value).  The container's
-                       max_nsyms then bounds the ranks, not the values.  With ANSX_FLAG_COMPACT_ALPHABET: the
+                       whose prelude would exceed 64 KiB (about 32 bits per distinct value).  A plain-ANSint
+                       container carries no parse hints and its max_nsyms bounds a block's DISTINCT values, so its bytes
+                       do not tell which of the two models wrote it.  With ANSX_FLAG_COMPACT_ALPHABET: the
                        harness's own layout, a block's dense ranks behind an alphabet header.  32-bit frequencies:
                        frames up to 2^27 (beyond, the reference's own 64-bit bound overflows) */
 } ansx_kind;

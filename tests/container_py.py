@@ -50,6 +50,9 @@ def build_container(kind, f, data, block, ckpt, wide=None):
         maxlg = max(maxlg, info.log2_frame)
         maxns = max(maxns, info.max_sym + 1)
         maxsig = max(maxsig, int(info.present_syms))  # symbols present in the block's model
+    if (kind & 0x1FF) == 3:  # plain ANSint: no parse hints, max_nsyms bounds a block's distinct values (dense and rank-space model alike)
+        hints = [np.zeros(8, dtype=np.uint32) for _ in hints]
+        maxns = maxsig
     if wide is None:
         wide = (kind & 0xFF) == 3 or maxlg > 16
     index_off = 64

@@ -92,9 +92,10 @@ def check_container(A, cont, data, kind, f, block, ckpt):
         assert np.array_equal(parts["ckpt_state"][b][:nck], st), b
         max_lg = max(max_lg, info.log2_frame)
         max_ns = max(max_ns, info.max_sym + 1)
-    if kind == ol.INT and not (H.kind & 0x100) and int(data.max()) >= 16384:
-        # plain ANSint beyond the dense model: modelled in rank space, the header bounds the ranks (distinct values per block)
+    if kind == ol.INT and not (H.kind & 0x100):
+        # plain ANSint: the header bounds a block's DISTINCT values, whichever model (dense, rank space) the call ran
         max_ns = max(np.unique(data[b * block:(b + 1) * block]).size for b in range(nblocks))
+        assert not parts["hints"].any() if "hints" in parts else True
     assert H.max_log2_frame == max_lg and H.max_nsyms == max_ns
     return parts
 
@@ -1634,6 +1635,29 @@ def test_plain_ansint_beyond_the_dense_model(A):
     assert ctx.last_encode_stats()["path"] & 256
     check_container(A, cont, d, ol.INT, 0, 65536, 1024)
     assert np.array_equal(codec.decode(cont, d.size), d)
+    # shards of one list, one with small values only (dense model), one with large ones (rank space): the merged container is the
+    # whole list's (no parse hints for plain ANSint, max_nsyms bounds the distinct values: nothing tells the two models apart)
+    torch = pytest.importorskip("torch")
+    block = 4096
+    small_part = (ol.gen_inputs("zipf20s1.2", 5 * block, seed=3) % np.uint32(9000)).astype(np.uint32)
+    large_part = ol.ansint_large_list(3 * block + 123, 1 << 21, 5, "skew")
+    whole_data = np.concatenate([small_part, large_part])
+    bufs, ptrs, sizes = [], [], []
+    for part in (small_part, large_part):
+        cs = A.Context(0)
+        cpart = A.ANSint(ctx=cs, block_ints=block, ckpt_interval=512, compact=False).encode(part)
+        cs.close()
+        t = torch.zeros(cpart.size + 64, dtype=torch.uint8, device="cuda")
+        t[:cpart.size] = torch.from_numpy(cpart.copy()).cuda()
+        bufs.append(t), ptrs.append(t.data_ptr()), sizes.append(cpart.size)
+    wcodec = A.ANSint(ctx=ctx, block_ints=block, ckpt_interval=512, compact=False)
+    whole = wcodec.encode(whole_data)
+    outb = torch.zeros(whole.size + 4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    nbm = ctx.merge_containers_dev(ptrs, sizes, outb.data_ptr(), outb.numel())
+    torch.cuda.synchronize()
+    assert nbm == whole.size and np.array_equal(outb[:nbm].cpu().numpy(), whole)
+    assert np.array_equal(wcodec.decode(whole, whole_data.size), whole_data)
     # out of reach (more than 16384 distinct values in a block): refused, not mis-coded
     big = ol.ansint_large_list(40000, 1 << 20, 3, "uniform")
     for kw in (dict(block_ints=A.SINGLE_STREAM), dict(block_ints=32768, ckpt_interval=1024)):

@@ -20,7 +20,7 @@ Round 4 (transposed decoder stores, speculative rings, the producer / consumer e
 at the end (the pair encoder as the default on ragged lists, plain ANSint on values up to 2^22 in half of its cases): 77 978 iterations
 (seed 104, 420 s), 3 436 calls through k_encode_pc, 2 226 ANSint calls modelled in rank space, 0 failures, 0 near-threshold decisions;
 at HEAD (blocks of any length in rank space, plain-ANSint containers without parse hints): 73 120 iterations (seed 211, 400 s; 3 343 through
-k_encode_pc, 2 901 in rank space) and 27 961 with SOAK_F67=1 (seed 221, 240 s), 0 failures.
+k_encode_pc, 2 901 in rank space), 163 809 (seed 307, 900 s; 7 497 / 6 287) and 27 961 with SOAK_F67=1 (seed 221, 240 s), 0 failures.
 """
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

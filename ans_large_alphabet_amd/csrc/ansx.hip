@@ -81,6 +81,8 @@ struct ansx_ctx {
     u32 cur_pa_distinct = 0;     // the same for the compaction layer's k_pa_remap (the hint itself)
     std::set<u64> int_sparse_hint;  // plain-ANSint geometries whose values outgrew the dense 16384-symbol model: rank space from the start
     bool cur_int_sparse = false;    // this call models its blocks in rank space (ansx_intsparse.h)
+    u32 sp_retries = 0;             // (tests) calls repeated with the full-size arrays
+    bool sp_full_lds = false;       // ... and its prelude writer runs with the full-size LDS arrays (a block's code outgrew the hint-sized ones)
     ansx_encode_stats last = {};
     // Path-selection overrides for tests and experiments (every path must give identical bytes).
     // Taken from the environment ONCE in ansx_init, changed afterwards only through ansx_debug_set;
@@ -100,6 +102,7 @@ struct ansx_ctx {
         bool use_pc = false;          // ANSX_USE_PC: k_encode_pc's chip-filling shape even under ANSX_NO_PC_AUTO
         u32 pc_b_pairs = 2;           // ANSX_PC_B_PAIRS: pairs per workgroup of shape B (2: one workgroup per CU -- 1.04 ms on BASELINE config 3;
                                       // 1: two workgroups per CU, whose waves the dispatcher does not spread as evenly -- 1.21 ms)
+        u32 test_sp_bits = 0;         // ANSX_TEST_SP_BITS: words of the sparse ANSint prelude writer's bit buffer on the first attempt (tests: forces its repeat)
         bool fin_one_wave = false;    // ANSX_FIN_ONE_WAVE: k_model_finish with one wave per block (alphabets up to 1024 slots)
         bool no_big_geo = false;      // ANSX_NO_BIG_GEO: no tabulated tree geometry for alphabets above 4096 slots
         bool no_pc_auto = false;      // ANSX_NO_PC_AUTO: never choose the pair kernel by itself (shapes A, B, C of launch_f64_encoder)
@@ -797,10 +800,15 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
             (u64)scr_stride, mostfreq, hints, pre_cap, geo);
     } else if (sparse) {
         // the reference's prelude over the VALUE range, from the rank-space model (16-byte entries: always16) and the block's values
-        const size_t sp_lds = (size_t)(2 * ANSX_SP_MAX_SIGMA + 2) * 4;
+        // LDS from the call's most distinct values per block (max_ns: read back above, the discovery path) unless a block's code
+        // outgrew three words per value on the first attempt
+        const u32 sp_cap = c->sp_full_lds ? (u32)ANSX_SP_MAX_SIGMA : std::min<u32>(ANSX_SP_MAX_SIGMA, (std::max<u32>(max_ns, 64u) + 63u) & ~63u);
+        const u32 sp_bits = c->sp_full_lds ? (u32)ANSX_SP_MAX_SIGMA
+                                           : (c->dbg.test_sp_bits ? c->dbg.test_sp_bits : std::min<u32>(ANSX_SP_MAX_SIGMA, 2u * sp_cap + 64u));
+        const size_t sp_lds = (size_t)(sp_cap + sp_bits + 2) * 4;
         HIPCHK(c, hipFuncSetAttribute((const void*)k_int_sparse_prelude, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_lds));
         LAUNCH(c, "k_int_sparse_prelude", k_int_sparse_prelude, NB, 256, sp_lds, s, g, NSP, (const u32*)c->pa_alpha.p,
-            (const ansx_enc_entry*)c->table.p, blk, (u8*)c->scratch.p, (u64)scr_stride, (u32)ANSX_SP_MAX_SIGMA, (u32)(4 * NSP), gflags);
+            (const ansx_enc_entry*)c->table.p, blk, (u8*)c->scratch.p, (u64)scr_stride, sp_cap, sp_bits, (u32)(4 * NSP), gflags);
     } else {
         const size_t gen_lds = (size_t)pre_cap * 8 + 64;  // (as long as the call's largest alphabet, not as its slot count: workgroups per CU)
         if (gen_lds > 150 * 1024) {  // f = 6, 7: the writer's two arrays in HBM
@@ -851,6 +859,13 @@ int encode_general(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size_
     }
     int st = flags_to_status(c->h_pin[ANSX_G_ERR]);
     if (st) return st;
+    if (sparse && !c->sp_full_lds && (c->h_pin[ANSX_G_ERR] & (1u << ANSX_G_VIOL_BIT))) {
+        c->sp_full_lds = true;  // (the value-range prelude of some block needs more than two words per distinct value)
+        c->sp_retries++;
+        const int rc2 = encode_general(c, P, d_in, d_out, cap, out_bytes, s, seen_ns, ns_cap);
+        c->sp_full_lds = false;
+        return rc2;
+    }
     *seen_ns = c->h_pin[ANSX_G_MAXNSYMS];
     u64 payload;
     memcpy(&payload, (u8*)c->h_pin + 16, 8);
@@ -1180,6 +1195,7 @@ int encode_dev_once(ansx_ctx* c, const Plan& P, const u32* d_in, u8* d_out, size
         rc = encode_general(c, P, d_in, d_out, cap, out_bytes, s, &seen, 0);
     }
     if (c->cur_int_sparse) path |= 256u;  // plain ANSint modelled in rank space
+    if (c->sp_retries) path |= 512u, c->sp_retries = 0;  // ... and repeated with the full-size prelude writer
     if (rc == ANSX_RETRY_WIDE) return rc;
     // close calls of the stop rule (counted by the exact kernels only; the fast path repeats on them): the host decides
     u32 redecided = 0;
@@ -1811,6 +1827,7 @@ int ansx_debug_set(ansx_ctx* c, const char* name, const char* value)
     else if (!strcmp(name, "ANSX_NO_PC_AUTO")) c->dbg.no_pc_auto = on;
     else if (!strcmp(name, "ANSX_NO_BIG_GEO")) c->dbg.no_big_geo = on;
     else if (!strcmp(name, "ANSX_FIN_ONE_WAVE")) c->dbg.fin_one_wave = on;
+    else if (!strcmp(name, "ANSX_TEST_SP_BITS")) c->dbg.test_sp_bits = value ? (u32)atoi(value) : 0u;
     else if (!strcmp(name, "ANSX_PC_B_PAIRS")) c->dbg.pc_b_pairs = (value && value[0] == '1') ? 1u : 2u;
     else if (!strcmp(name, "ANSX_ENCODE_MODE2")) c->dbg.encode_mode2 = on;
     else if (!strcmp(name, "ANSX_DECODE_SMALL_RING"))

@@ -52,7 +52,10 @@ __device__ __forceinline__ void sp_walk(const u32* __restrict__ vals, const ansx
     const long long prev = j ? (long long)vals[j - 1] : -1ll;
     const u32 Cprev = tab[j].base, Cj = Cprev + tab[j].freq;
     auto mass_upto = [&](u32 t) -> u32 {  // frequency mass of the symbols <= t, for t >= s
-        const u32 idx = sp_count_le(vals, j, sigma, t);
+        // (galloping from j: deep in the tree t is a few symbols to the right of s, and these reads go to L2)
+        u32 bound = 1;
+        while (j + bound < sigma && vals[j + bound] <= t) bound <<= 1;
+        const u32 idx = sp_count_le(vals, j + (bound >> 1), j + bound < sigma ? j + bound : sigma, t);
         return idx < sigma ? tab[idx].base : M;
     };
     u32 a = 0, n = N;
@@ -93,12 +96,15 @@ __device__ __forceinline__ void sp_walk(const u32* __restrict__ vals, const ansx
     }
 }
 
-// One workgroup of 256 threads per block.  Dynamic LDS: off[sigma_cap] + bits[sigma_cap + 2] words.
+// One workgroup of 256 threads per block.  Dynamic LDS: off[sigma_cap] + bits[bits_cap + 2] words, sized by the host from the
+// call's most distinct values per block (read back with the model's other maxima) so that several workgroups share a CU -- a
+// workgroup is a chain of dependent L2 reads; bits_cap = 2 words per distinct value (+ 64): a block whose code is longer raises the
+// violation flag and the host repeats the call with the full 16384 + 16384 words.
 // limit_bytes: room for vbyte + log2 M + code in the block's scratch slot (the model's 4 x 16384 bytes); a prelude
 // that does not fit fails the call with ANSX_ERR_DOMAIN (it would take ~32 bits per distinct value).
 __global__ __launch_bounds__(256) void k_int_sparse_prelude(ansx_geo g, u32 NSP, const u32* __restrict__ alpha,
     const ansx_enc_entry* __restrict__ table, ansx_blk* __restrict__ blk, u8* __restrict__ scratch, u64 scr_stride,
-    u32 sigma_cap, u32 limit_bytes, u32* __restrict__ gflags)
+    u32 sigma_cap, u32 bits_cap, u32 limit_bytes, u32* __restrict__ gflags)
 {
     extern __shared__ u32 sp_lds[];
     __shared__ u32 sh_part[8];
@@ -111,6 +117,14 @@ __global__ __launch_bounds__(256) void k_int_sparse_prelude(ansx_geo g, u32 NSP,
     u32* off = sp_lds;
     u32* bits = sp_lds + sigma_cap;
     const u32 sigma = B->sp_sigma;
+    if (sigma > sigma_cap) {  // (cannot happen: the cap is the call's maximum)
+        if (tid == 0) {
+            B->prelude_bytes = 0;
+            B->status = 1;
+            atomicOr(&gflags[ANSX_G_ERR], 1u << ANSX_G_VIOL_BIT);
+        }
+        return;
+    }
     const u32 logM = B->logM, M = 1u << logM;
     const u32* vals = alpha + (u64)b * g.block_ints;
     const ansx_enc_entry* tab = table + (u64)b * NSP;
@@ -138,11 +152,11 @@ __global__ __launch_bounds__(256) void k_int_sparse_prelude(ansx_geo g, u32 NSP,
     u32 vb = 1;
     for (u32 t = ms; t >= 128; t >>= 7) vb++;
     const u32 p = vb + 1;
-    if (p + nwords * 4 > limit_bytes || nwords > sigma_cap) {  // (workgroup-uniform)
+    if (p + nwords * 4 > limit_bytes || nwords > bits_cap) {  // (workgroup-uniform)
         if (tid == 0) {
             B->prelude_bytes = 0;
             B->status = 1;  // the encoder skips the block
-            atomicOr(&gflags[ANSX_G_ERR], 1u << 6 /* ANSX_ERR_DOMAIN */);
+            atomicOr(&gflags[ANSX_G_ERR], p + nwords * 4 > limit_bytes ? 1u << 6 /* ANSX_ERR_DOMAIN */ : 1u << ANSX_G_VIOL_BIT);
         }
         return;
     }
@@ -225,25 +239,50 @@ __global__ __launch_bounds__(64) void k_int_sparse_parse(const u8* __restrict__ 
         u32 a = 0, n = N, low = 1, high = u + 1;
         long long tprev = -1, incprev = -1;  // inc[-1] = -1: inc[t] - t is the mass up to t
         u32 mass = 0;
-        // One node per iteration (a single flat loop: every lane walks another block): decode the node and go left, or --
-        // the node is empty or silent -- report the item on top of the stack and go right of it.
+        // A single flat loop (every lane walks another block, so both halves of the body run for the wave anyway): (1) if the
+        // current node is empty or silent, report the item on top of the stack and move to its right subtree; (2) decode the
+        // current node, if it carries bits, and go left.  One pop and one decode per iteration: as many iterations as nodes.
+        auto shape = [&](u32& h, u32& n1, u32& n2, u32& U) -> bool {  // node (n != 0): its split and code range; false = malformed
+            h = (n + 1) >> 1, n1 = h - 1, n2 = n - h;
+            if (high < n2 + low + n1 || total_bits > maxbits || sp >= 32) return false;
+            U = high - n2 - low - n1 + 1;
+            return U <= u + 1;
+        };
         for (;;) {
-            bool descend = n != 0;
             u32 U = 1, h = 0, n1 = 0, n2 = 0;
-            if (descend) {
-                h = (n + 1) >> 1, n1 = h - 1, n2 = n - h;
-                if (high < n2 + low + n1 || total_bits > maxbits || sp >= 32) {
-                    err = 1;
-                    break;
-                }
-                U = high - n2 - low - n1 + 1;
-                if (U > u + 1) {
-                    err = 1;
-                    break;
-                }
-                descend = U != 1;  // silent: so is everything below
+            if (n != 0 && !shape(h, n1, n2, U)) {
+                err = 1;
+                break;
             }
-            if (descend) {
+            if (n == 0 || U == 1) {  // empty, or silent (and so is everything below)
+                if (sp == 0) break;
+                sp--;
+                const uint4 e = stk[sp][lane];
+                const long long t = e.x, inc = (long long)e.y - 1;
+                const long long nf = inc - incprev - (t - tprev);
+                if (nf < 0 || nf > (long long)M || (nf > 0 && sigma >= cap)) {
+                    err = 1;
+                    break;
+                }
+                if (nf > 0) {
+                    mass += (u32)nf;
+                    al[sigma] = (u32)t;
+                    cum[sigma + 1] = mass + sigma;
+                    sigma++;
+                }
+                tprev = t;
+                incprev = inc;
+                a = e.x + 1;  // right subtree
+                n = e.z;
+                low = e.y + 1;
+                high = e.w;
+                U = 1;
+                if (n != 0 && !shape(h, n1, n2, U)) {
+                    err = 1;
+                    break;
+                }
+            }
+            if (n != 0 && U != 1) {
                 const u32 bb = 32 - __clz(U - 1);  // read_center_mid (interp.hpp:47-63)
                 const u32 mth = (u32)((1ull << bb) - U);
                 const u32 dh = U - (1u << (bb - 1));
@@ -256,29 +295,9 @@ __global__ __launch_bounds__(64) void k_int_sparse_parse(const u8* __restrict__ 
                 sp++;
                 n = n1;
                 high = v - 1;
-                continue;
+            } else if (n != 0) {
+                n = 0;  // silent right subtree: the next iteration pops again
             }
-            if (sp == 0) break;
-            sp--;
-            const uint4 e = stk[sp][lane];
-            const long long t = e.x, inc = (long long)e.y - 1;
-            const long long nf = inc - incprev - (t - tprev);
-            if (nf < 0 || nf > (long long)M || (nf > 0 && sigma >= cap)) {
-                err = 1;
-                break;
-            }
-            if (nf > 0) {
-                mass += (u32)nf;
-                al[sigma] = (u32)t;
-                cum[sigma + 1] = mass + sigma;
-                sigma++;
-            }
-            tprev = t;
-            incprev = inc;
-            a = e.x + 1;  // right subtree
-            n = e.z;
-            low = e.y + 1;
-            high = e.w;
         }
         if (!err && (mass != M || sigma == 0 || (long long)(N - 1) != tprev)) err = 1;  // the last item (max_sym) is present
     }

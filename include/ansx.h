@@ -219,7 +219,8 @@ int ansx_profile_get(ansx_ctx* ctx, ansx_kernel_time* out, int max_entries, int*
  *                             FIRST); + 64: the remembered wide form was not needed by this input and the call was
  *                             repeated with packed restart points; + 128: the producer / consumer encoder kernel
  *                             (k_encode_pc) ran; + 256: plain ANSint modelled in rank space (values of 16384 and more; remembered per geometry
- *                             as the attempt to run first, and given up again by a call whose values are small).  Either way the output bytes -- the restart-point
+ *                             as the attempt to run first, and given up again by a call whose values are small); + 512: that call was repeated with
+ *                             the full-size arrays of the value-range prelude writer.  Either way the output bytes -- the restart-point
  *                             format included -- are a function of the input and the options only. */
 typedef struct {
     uint32_t max_nsyms;

@@ -1635,6 +1635,18 @@ def test_plain_ansint_beyond_the_dense_model(A):
         assert np.array_equal(codec.encode(d), cont)
         c1.close()
         c2.close()
+    # the prelude writer sizes its bit buffer from the call's distinct-value maximum (two words per value) and the call is
+    # repeated with the full size when a block's code is longer: forced here, same bytes
+    d = ol.ansint_large_list(30000, 1 << 22, 41, "skew")
+    c3 = A.Context(0)
+    ref = A.ANSint(ctx=c3, block_ints=8192, ckpt_interval=1024, compact=False).encode(d)
+    assert not (c3.last_encode_stats()["path"] & 512)
+    c3.close()
+    c3 = A.Context(0)
+    c3.debug_set("ANSX_TEST_SP_BITS", "40")
+    got = A.ANSint(ctx=c3, block_ints=8192, ckpt_interval=1024, compact=False).encode(d)
+    assert c3.last_encode_stats()["path"] & 512 and np.array_equal(got, ref)
+    c3.close()
     # a block in which every int is a different large value (16384 ranks: the model's last symbol is used)
     ctx = A.Context(0)
     d = (np.arange(16384, dtype=np.uint32) * np.uint32(977) + np.uint32(50000))

@@ -255,8 +255,12 @@ int ansx_generate_host(int dist, double a, double b, uint64_t seed, uint64_t fir
  * the stop-rule threshold inside which the fast path repeats on the exact one / the host re-decides),
  * ANSX_TEST_NEAR_FLIP (the device decides close calls the wrong way), ANSX_CAND_CHAINS (1 | 2), ANSX_WIDE_RESTART
  * (wide restart points in every container -- the one switch here that changes the output: the index, not the block
- * streams), ANSX_TEST_WIDE_AT (number <= 16: frames above 2^this count as too large for packed restart points)
- * (flags: "1" on, "0"/""/NULL off).  Unknown name: ANSX_ERR_ARG. */
+ * streams), ANSX_TEST_WIDE_AT (number <= 16: frames above 2^this count as too large for packed restart points);
+ * through this call only (round 4): ANSX_NO_PC / ANSX_FORCE_PC / ANSX_NO_PC_AUTO / ANSX_PC_B_PAIRS (the producer /
+ * consumer encoder never / whatever the list length / only on request; pairs per workgroup of its two-round shape),
+ * ANSX_ENCODE_MODE2, ANSX_DECODE_PAIR, ANSX_DECODE_SMALL_RING (1 never | 2 always), ANSX_FORGET_HINTS, ANSX_NO_BIG_GEO,
+ * ANSX_FIN_ONE_WAVE, ANSX_TEST_SP_BITS (number: words of the rank-space ANSint prelude writer's bit buffer on its first
+ * attempt)  (flags: "1" on, "0"/""/NULL off).  Unknown name: ANSX_ERR_ARG. */
 int ansx_debug_set(ansx_ctx* ctx, const char* name, const char* value);
 
 /* Bytes of device workspace currently held by the context. */
